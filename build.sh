@@ -1,0 +1,32 @@
+#!/bin/bash
+# Build every native artefact in-tree.  __graft_entry__.build() drives this script.
+#   host   : hexray_amd/lib/libhexray_host.so   (C++17, loader + flattener)
+#   hip    : hexray_amd/lib/libhexray_hip.so    (HIP, gfx950 render module, the C-ABI drop-in)
+#   cli    : hexray_amd/bin/hexray              (headless main() replacement)
+#   oracle : oracle/liboracle.so                (C restatement; test infrastructure only)
+#   ref    : oracle/_ref/...                    (only when /root/reference is present)
+set -e
+cd "$(dirname "$0")"
+what="${1:-all}"
+mkdir -p hexray_amd/lib hexray_amd/bin
+# host flags = the reference Release flags (CMakeLists.txt:80): the kd builder only reproduces the
+# reference tree bit-for-bit (SURVEY.md 8c(iv) statistics) when FMA contraction matches.
+CXXFLAGS="-std=c++17 -O3 -ffast-math -march=haswell -mtune=haswell -fPIC -Wall -Wno-unused-function -Iinclude -Ihexray_amd/host"
+HOST_SRC="hexray_amd/host/scene_file.cpp hexray_amd/host/image_io.cpp hexray_amd/host/exr_reader.cpp hexray_amd/host/mesh_prep.cpp hexray_amd/host/heightfield_prep.cpp hexray_amd/host/flatten.cpp hexray_amd/host/host_api.cpp"
+if [ "$what" = all ] || [ "$what" = host ]; then
+	g++ $CXXFLAGS -shared -o hexray_amd/lib/libhexray_host.so $HOST_SRC
+fi
+if [ "$what" = all ] || [ "$what" = oracle ]; then
+	make -s -C oracle liboracle.so
+fi
+if [ "$what" = all ] || [ "$what" = hip ]; then
+	hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Ihexray_amd/csrc \
+		-o hexray_amd/lib/libhexray_hip.so hexray_amd/csrc/hxr_api.hip
+fi
+if [ "$what" = all ] || [ "$what" = cli ]; then
+	g++ $CXXFLAGS -o hexray_amd/bin/hexray hexray_amd/host/main.cpp -Lhexray_amd/lib -lhexray_host -ldl \
+		-Wl,-rpath,'$ORIGIN/../lib'
+fi
+if [ "$what" = all ] || [ "$what" = ref ]; then
+	if [ -d /root/reference/src ]; then make -s -C oracle ref; fi
+fi

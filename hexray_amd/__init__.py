@@ -1,0 +1,359 @@
+"""hexray_amd -- MI355X-native render path for heX-Ray scenes.
+
+Thin ctypes binding over the two native libraries of the product:
+
+* ``lib/libhexray_host.so`` -- the host side that stays on the CPU: ``.hexray`` loader, scene
+  flattening, camera, bitmap output (``hexray_amd/host``; mirrors reference ``src/scene.cpp``,
+  ``src/mesh.cpp:49-122,265-396``, ``src/camera.cpp:30-63``, ``src/bitmap.cpp``).
+* ``lib/libhexray_hip.so`` -- the C-ABI render module of hand-written HIP kernels for gfx950
+  (``include/hexray_hip.h``; replaces reference ``render()``, ``src/main.cpp:416-426``).
+
+There is no CPU fallback: rendering without the HIP library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libhexray_host.so")
+HIP_LIB_PATH = os.path.join(_HERE, "lib", "libhexray_hip.so")
+
+MODE_AUTO, MODE_SINGLE, MODE_ADAPTIVE_AA, MODE_MONTE_CARLO = 0, 1, 2, 3
+LAYOUT_FRAME, LAYOUT_TILES = 0, 1
+DEFAULT_SEED = 5489
+
+
+class FrameParams(ctypes.Structure):
+    """hxr_frame_params (include/hexray_hip.h)."""
+
+    _fields_ = [
+        ("width", c_int32), ("height", c_int32), ("mode", c_int32), ("spp", c_int32),
+        ("rng_seed", c_uint64),
+        ("tile_size", c_int32), ("shard_rank", c_int32), ("shard_count", c_int32), ("layout", c_int32),
+        ("collect_counters", c_int32), ("reserved_", c_int32 * 5),
+    ]
+
+
+COUNTER_FIELDS = [
+    "camera_samples", "raycasts", "shadow_queries", "node_tests", "bbox_tests", "kd_visits", "leaf_indices",
+    "tri_tests", "mesh_hits", "tex_bilinear", "env_bilinear", "hf_calls", "hf_highest", "hf_height",
+    "hf_tri_tests", "hf_normals", "aa_pixels",
+]
+
+
+class Counters(ctypes.Structure):
+    """hxr_counters (include/hexray_hip.h)."""
+
+    _fields_ = [(n, c_uint64) for n in COUNTER_FIELDS] + [("reserved_", c_uint64 * 7)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
+
+
+def frame_params(width=0, height=0, mode=MODE_AUTO, spp=0, seed=DEFAULT_SEED, tile_size=0, shard_rank=0,
+                 shard_count=1, layout=LAYOUT_FRAME, collect_counters=False) -> FrameParams:
+    p = FrameParams()
+    p.width, p.height, p.mode, p.spp = width, height, mode, spp
+    p.rng_seed = seed
+    p.tile_size, p.shard_rank, p.shard_count, p.layout = tile_size, shard_rank, shard_count, layout
+    p.collect_counters = 1 if collect_counters else 0
+    return p
+
+
+_host = None
+
+
+def host_lib():
+    """libhexray_host.so (loader + flattener); raises if it has not been built."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run ./build.sh (or __graft_entry__.build())")
+        lib = ctypes.CDLL(HOST_LIB_PATH)
+        lib.hxh_scene_load.restype = c_void_p
+        lib.hxh_scene_load.argtypes = [c_char_p, c_char_p, c_char_p, c_size_t]
+        lib.hxh_scene_desc.restype = c_void_p
+        lib.hxh_scene_desc.argtypes = [c_void_p]
+        lib.hxh_scene_free.argtypes = [c_void_p]
+        for name in ("hxh_scene_num_threads", "hxh_scene_prepass_samples", "hxh_scene_interactive", "hxh_scene_num_warnings"):
+            getattr(lib, name).argtypes = [c_void_p]
+        lib.hxh_scene_warning.restype = c_char_p
+        lib.hxh_scene_warning.argtypes = [c_void_p, c_int]
+        lib.hxh_scene_kd_stats.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double), POINTER(c_double)]
+        lib.hxh_camera_move.argtypes = [c_void_p, c_double, c_double]
+        lib.hxh_camera_rotate.argtypes = [c_void_p, c_double, c_double]
+        lib.hxh_bucket_list.argtypes = [c_int, c_int, c_int, POINTER(c_int), c_int]
+        lib.hxh_save_bmp.argtypes = [c_char_p, c_void_p, c_int, c_int, c_size_t]
+        lib.hxh_save_raw.argtypes = [c_char_p, c_void_p, c_int, c_int, c_size_t]
+        lib.hxh_srgb8.restype = ctypes.c_uint
+        lib.hxh_srgb8.argtypes = [c_float]
+        lib.hxh_load_image.restype = POINTER(c_float)
+        lib.hxh_load_image.argtypes = [c_char_p, POINTER(c_int), POINTER(c_int)]
+        lib.hxh_free_pixels.argtypes = [POINTER(c_float)]
+        _host = lib
+    return _host
+
+
+class HostScene:
+    """A parsed, prepared and flattened ``.hexray`` scene (host memory).
+
+    ``overlay`` is extra scene text in the same syntax whose blocks override properties of the
+    matching blocks of the file -- the reference can only take W x H / spp / AA from the scene file
+    (reference src/scene.cpp:764-778, src/camera.h:57-72), so overrides are expressed the same way.
+    """
+
+    def __init__(self, path: str, overlay: str = ""):
+        lib = host_lib()
+        err = ctypes.create_string_buffer(1024)
+        self._h = lib.hxh_scene_load(os.fsencode(path), overlay.encode(), err, len(err))
+        if not self._h:
+            raise ValueError(f"cannot load scene {path}: {err.value.decode(errors='replace')}")
+        self.path = path
+
+    @property
+    def desc(self) -> int:
+        """Address of the hxr_scene_desc (valid while this object lives)."""
+        return host_lib().hxh_scene_desc(self._h)
+
+    @property
+    def settings(self):
+        return SceneDescHeader.from_address(self.desc).settings
+
+    @property
+    def camera(self):
+        return SceneDescHeader.from_address(self.desc).camera
+
+    @property
+    def warnings(self):
+        lib = host_lib()
+        return [lib.hxh_scene_warning(self._h, i).decode() for i in range(lib.hxh_scene_num_warnings(self._h))]
+
+    def kd_stats(self):
+        """Per mesh: (nodes, leaf nodes, max depth, avg depth, avg tris per leaf) as Mesh::beginRender prints them."""
+        lib, out, m = host_lib(), [], 0
+        while True:
+            a, b, c, d, e = c_int(), c_int(), c_int(), c_double(), c_double()
+            if lib.hxh_scene_kd_stats(self._h, m, a, b, c, d, e) != 0:
+                return out
+            out.append((a.value, b.value, c.value, d.value, e.value))
+            m += 1
+
+    def move_camera(self, sideways: float, front_back: float):
+        host_lib().hxh_camera_move(self._h, sideways, front_back)
+
+    def rotate_camera(self, yaw: float, pitch: float):
+        host_lib().hxh_camera_rotate(self._h, yaw, pitch)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host_lib().hxh_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Settings(ctypes.Structure):
+    _fields_ = [("ambient", c_float * 3), ("background", c_float * 3), ("max_trace_depth", c_int32), ("want_aa", c_int32),
+                ("gi", c_int32), ("num_paths", c_int32), ("frame_width", c_int32), ("frame_height", c_int32)]
+
+
+class Camera(ctypes.Structure):
+    _fields_ = [("pos", c_double * 3), ("top_left", c_double * 3), ("top_right", c_double * 3), ("bottom_left", c_double * 3),
+                ("up", c_double * 3), ("right", c_double * 3), ("front", c_double * 3), ("aperture_size", c_double),
+                ("focal_plane_dist", c_double), ("stereo_separation", c_double), ("dof", c_int32), ("num_samples", c_int32),
+                ("auto_focus", c_int32), ("pad_", c_int32)]
+
+
+class SceneDescHeader(ctypes.Structure):
+    """Leading fields of hxr_scene_desc (enough to read settings / camera from Python)."""
+
+    _fields_ = [("abi_version", ctypes.c_uint32), ("reserved_", ctypes.c_uint32), ("settings", Settings), ("camera", Camera)]
+
+
+def bucket_list(width: int, height: int, bucket_size: int = 64):
+    """The reference's zig-zag bucket order (src/sdl.cpp:280-294) as an (n, 4) int array x0,y0,x1,y1."""
+    lib = host_lib()
+    n = lib.hxh_bucket_list(width, height, bucket_size, None, 0)
+    buf = (c_int * (4 * n))()
+    lib.hxh_bucket_list(width, height, bucket_size, buf, n)
+    return np.frombuffer(buf, dtype=np.int32).reshape(n, 4).copy()
+
+
+def save_bmp(path: str, frame: np.ndarray):
+    """Write a float RGB frame as 24-bit sRGB BMP exactly like Bitmap::saveBMP (src/bitmap.cpp:190-240)."""
+    f = np.ascontiguousarray(frame, dtype=np.float32)
+    h, w, _ = f.shape
+    if host_lib().hxh_save_bmp(os.fsencode(path), f.ctypes.data, w, h, w * 12) != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def load_image(path: str) -> np.ndarray:
+    lib = host_lib()
+    w, h = c_int(), c_int()
+    p = lib.hxh_load_image(os.fsencode(path), w, h)
+    if not p:
+        raise OSError(f"cannot load {path}")
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.hxh_free_pixels(p)
+
+
+_hip = None
+
+
+def hip_lib():
+    """libhexray_hip.so, the C-ABI render module.  Raises if it is missing -- there is no fallback."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(f"{HIP_LIB_PATH} is missing: run ./build.sh (or __graft_entry__.build()); there is no CPU fallback")
+        lib = ctypes.CDLL(HIP_LIB_PATH)
+        lib.hxr_device_count.restype = c_int
+        lib.hxr_init.argtypes = [c_int]
+        lib.hxr_scene_create.restype = c_void_p
+        lib.hxr_scene_create.argtypes = [c_void_p]
+        lib.hxr_scene_update_camera.argtypes = [c_void_p, c_void_p]
+        lib.hxr_render.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
+        lib.hxr_render_device.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p]
+        lib.hxr_output_bytes.restype = c_size_t
+        lib.hxr_output_bytes.argtypes = [c_void_p, POINTER(FrameParams), c_size_t]
+        lib.hxr_shard_tile_count.argtypes = [c_void_p, POINTER(FrameParams)]
+        lib.hxr_shard_tile_rect.argtypes = [c_void_p, POINTER(FrameParams), c_int] + [POINTER(c_int)] * 4
+        lib.hxr_assemble_frame.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
+        lib.hxr_quantize_srgb8.argtypes = [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]
+        lib.hxr_get_counters.argtypes = [c_void_p, POINTER(Counters)]
+        lib.hxr_last_kernel_ms.restype = c_double
+        lib.hxr_last_kernel_ms.argtypes = [c_void_p]
+        lib.hxr_scene_destroy.argtypes = [c_void_p]
+        lib.hxr_last_error.restype = c_char_p
+        _hip = lib
+    return _hip
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _check(code: int, what: str):
+    if code < 0:
+        raise HipError(f"{what} failed ({code}): {hip_lib().hxr_last_error().decode(errors='replace')}")
+    return code
+
+
+_initialised_device = None
+
+
+def init(device_id: int = 0):
+    """Bind this process to one GPU (one process per GPU)."""
+    global _initialised_device
+    lib = hip_lib()
+    if lib.hxr_device_count() <= 0:
+        raise HipError("no gfx950 device visible: the render path has no CPU fallback")
+    _check(lib.hxr_init(device_id), "hxr_init")
+    _initialised_device = device_id
+
+
+class DeviceScene:
+    """A scene resident in HBM (hxr_scene)."""
+
+    def __init__(self, host_scene: HostScene):
+        if _initialised_device is None:
+            init(0)
+        self._s = hip_lib().hxr_scene_create(host_scene.desc)
+        if not self._s:
+            raise HipError("hxr_scene_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))
+        self.host = host_scene
+
+    def update_camera(self):
+        cam_addr = ctypes.addressof(SceneDescHeader.from_address(self.host.desc).camera)
+        _check(hip_lib().hxr_scene_update_camera(self._s, cam_addr), "hxr_scene_update_camera")
+
+    def frame_size(self, params: FrameParams):
+        s = self.host.settings
+        return (params.width or s.frame_width, params.height or s.frame_height)
+
+    def render(self, params: FrameParams | None = None) -> np.ndarray:
+        """Blocking render into a host float32 array of shape (H, W, 3): the reference's vfb."""
+        params = params or frame_params()
+        w, h = self.frame_size(params)
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        _check(hip_lib().hxr_render(self._s, ctypes.byref(params), out.ctypes.data, w * 12, None, None, None), "hxr_render")
+        return out
+
+    def render_device(self, params: FrameParams, d_out: int, row_stride_bytes: int, stream: int = 0):
+        """Asynchronous render into device memory at address ``d_out`` on HIP stream ``stream``."""
+        _check(hip_lib().hxr_render_device(self._s, ctypes.byref(params), d_out, row_stride_bytes, stream), "hxr_render_device")
+
+    def output_bytes(self, params: FrameParams, row_stride_bytes: int) -> int:
+        return hip_lib().hxr_output_bytes(self._s, ctypes.byref(params), row_stride_bytes)
+
+    def shard_tiles(self, params: FrameParams):
+        lib = hip_lib()
+        n = lib.hxr_shard_tile_count(self._s, ctypes.byref(params))
+        rects = np.zeros((n, 4), dtype=np.int32)
+        for i in range(n):
+            a, b, c, d = c_int(), c_int(), c_int(), c_int()
+            lib.hxr_shard_tile_rect(self._s, ctypes.byref(params), i, a, b, c, d)
+            rects[i] = (a.value, b.value, c.value, d.value)
+        return rects
+
+    def assemble_frame(self, params: FrameParams, d_gathered: int, per_rank_bytes: int, d_frame: int, row_stride_bytes: int, stream: int = 0):
+        _check(hip_lib().hxr_assemble_frame(self._s, ctypes.byref(params), d_gathered, per_rank_bytes, d_frame, row_stride_bytes, stream), "hxr_assemble_frame")
+
+    def counters(self) -> dict:
+        c = Counters()
+        _check(hip_lib().hxr_get_counters(self._s, ctypes.byref(c)), "hxr_get_counters")
+        return c.as_dict()
+
+    def last_kernel_ms(self) -> float:
+        return hip_lib().hxr_last_kernel_ms(self._s)
+
+    def close(self):
+        if getattr(self, "_s", None):
+            hip_lib().hxr_scene_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def overlay_text(width=None, height=None, want_aa=None, dof=None, num_samples=None, gi=None, num_paths=None,
+                 prepass_samples=0, interactive=False, extra: str = "") -> str:
+    """Build the overlay text for the configs of SURVEY.md section 8d."""
+    g, c = [], []
+    if width is not None:
+        g.append(f"frameWidth {width}")
+    if height is not None:
+        g.append(f"frameHeight {height}")
+    if want_aa is not None:
+        g.append(f"wantAA {'on' if want_aa else 'off'}")
+    if gi is not None:
+        g.append(f"gi {'on' if gi else 'off'}")
+    if num_paths is not None:
+        g.append(f"numPaths {num_paths}")
+    if prepass_samples is not None:
+        g.append(f"prepassSamples {prepass_samples}")
+    if interactive is not None:
+        g.append(f"interactive {'on' if interactive else 'off'}")
+    if dof is not None:
+        c.append(f"dof {'on' if dof else 'off'}")
+    if num_samples is not None:
+        c.append(f"numSamples {num_samples}")
+    text = ""
+    if g:
+        text += "GlobalSettings {\n" + "\n".join(g) + "\n}\n"
+    if c:
+        text += "Camera {\n" + "\n".join(c) + "\n}\n"
+    return text + extra

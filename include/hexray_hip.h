@@ -1,0 +1,358 @@
+/*
+ * hexray_hip.h -- C ABI of the MI355X render module (libhexray_hip.so).
+ *
+ * This is the drop-in boundary for heX-Ray's per-pixel / per-sample raytrace loop.  The reference
+ * has no FFI: its seam is `bool render(bool displayProgress)` (reference src/main.cpp:416-426), which
+ * reads the global `Scene scene` (src/scene.h:271-294) and writes the global
+ * `Color vfb[VFB_MAX_SIZE][VFB_MAX_SIZE]` (src/main.cpp:50).  A host that keeps the reference's loader,
+ * scene graph, camera and bitmap output flattens its Scene once into `hxr_scene_desc` (plain arrays,
+ * no pointers inside records), hands it to `hxr_scene_create`, and calls `hxr_render` where the
+ * reference calls `renderWithoutMonteCarlo` / `renderWithMonteCarlo` (src/main.cpp:253-384).
+ * INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no torch / HIP types in any signature (a stream is `void*`).
+ *   - every record mirrors a reference class; the citation next to it names the fields it carries.
+ *   - vectors are 3 doubles, colours 3 floats (reference src/vector.h:30-34, src/color.h:62-68).
+ *   - matrices are row-major 3x3 used with ROW vectors, v' = v * M (reference src/matrix.h:53-60).
+ *   - indices are 0-based into the tables of the same descriptor; -1 means "none".
+ *   - all functions return 0 on success, a negative HXR_E_* code on failure; nothing throws.
+ */
+#ifndef HEXRAY_HIP_H
+#define HEXRAY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HXR_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------ error codes */
+enum {
+	HXR_OK = 0,
+	HXR_CANCELLED = 1,        /* hxr_render only: the cancel flag was raised (reference render() returns false) */
+	HXR_E_INVALID = -1,       /* bad argument / malformed descriptor */
+	HXR_E_NO_DEVICE = -2,     /* no usable gfx950 device, or hxr_init not called */
+	HXR_E_HIP = -3,           /* a HIP runtime call failed; see hxr_last_error() */
+	HXR_E_UNSUPPORTED = -4,   /* scene uses a feature this build does not render */
+	HXR_E_NOMEM = -5
+};
+
+/* ------------------------------------------------------------------ element tables */
+
+/* Transform (reference src/matrix.h:65-99): offset, m, invM, transposedInverse. */
+typedef struct hxr_transform {
+	double offset[3];
+	double m[9];
+	double inv_m[9];
+	double tinv_m[9];
+} hxr_transform;
+
+enum hxr_geom_type {
+	HXR_GEOM_PLANE = 0,       /* src/geometry.h:57-67   p = {y, limit} */
+	HXR_GEOM_SPHERE = 1,      /* src/geometry.h:69-81   p = {Ox, Oy, Oz, R, uvscaling} */
+	HXR_GEOM_CUBE = 2,        /* src/geometry.h:83-107  p = {Ox, Oy, Oz, halfSide} */
+	HXR_GEOM_CSG_UNION = 3,   /* src/geometry.h:109-136 left/right = geometry indices */
+	HXR_GEOM_CSG_INTER = 4,
+	HXR_GEOM_CSG_DIFF = 5,
+	HXR_GEOM_MESH = 6,        /* src/mesh.h:75-119      ref = index into meshes[] */
+	HXR_GEOM_HEIGHTFIELD = 7  /* src/heightfield.h:30-52 ref = index into heightfields[] */
+};
+
+typedef struct hxr_geometry {
+	int32_t type;
+	int32_t left, right;
+	int32_t ref;
+	double p[6];
+} hxr_geometry;
+
+/* Triangle (reference src/bbox.h:36-43), same fields, indices local to the owning mesh. */
+typedef struct hxr_triangle {
+	int32_t v[3], n[3], t[3];
+	int32_t pad_;
+	double gnormal[3];
+	double AB[3], AC[3], ABcrossAC[3];
+	double dNdx[3], dNdy[3];
+} hxr_triangle;
+
+/* KDTreeNode (reference src/mesh.h:32-60) flattened: children are stored as an adjacent pair. */
+typedef struct hxr_kd_node {
+	int32_t axis;      /* 0,1,2 = split axis of a binary node; 3 = leaf (AXIS_NONE) */
+	int32_t first;     /* binary: index of the LEFT child (right = first+1), local to the mesh;
+	                      leaf  : index of its first entry in the mesh's leaf-index list */
+	int32_t count;     /* leaf: number of triangle indices; binary: 0 */
+	int32_t parent;    /* local index of the parent node, -1 for the root */
+	double split;      /* splitPos (binary nodes) */
+} hxr_kd_node;
+
+/* Mesh (reference src/mesh.h:75-119).  Offsets are ELEMENT offsets into the descriptor's pools. */
+typedef struct hxr_mesh {
+	int32_t faceted, backface_culling, has_kd, pad_;
+	double bbox_min[3], bbox_max[3];
+	/* vertex / normal / uv arrays live in f64_pool as 3-double vectors; first_* counts VECTORS:
+	   component c of element e is f64_pool[(first_vertex + e) * 3 + c]; element 0 is the OBJ sentinel */
+	int64_t first_vertex, num_vertices;
+	int64_t first_normal, num_normals;
+	int64_t first_uv, num_uvs;               /* (u, v, 0) */
+	int64_t first_triangle, num_triangles;   /* triangles[] */
+	int64_t first_kd_node, num_kd_nodes;     /* kd_nodes[]; node 0 of the range is the root */
+	int64_t first_leaf_index, num_leaf_indices; /* leaf_indices[] (triangle numbers local to the mesh) */
+} hxr_mesh;
+
+/* Heightfield (reference src/heightfield.h:30-52). */
+typedef struct hxr_heightfield {
+	int32_t W, H, max_k, use_optimization;
+	double bbox_min[3], bbox_max[3];
+	int64_t first_height;    /* f32_pool, W*H            heights[y*W+x] */
+	int64_t first_maxh;      /* f32_pool, W*H            maxH[y*W+x]    */
+	int64_t first_highmap;   /* f32_pool, W*H*16         highMap[y*W+x].h[k] */
+	int64_t first_normal;    /* f64_pool, counted in 3-double VECTORS like hxr_mesh: normals[y*W+x] */
+} hxr_heightfield;
+
+/* Bitmap (reference src/bitmap.h:32-63): float RGB texels, row-major, 3 floats per texel. */
+typedef struct hxr_bitmap {
+	int32_t width, height;
+	int64_t first_texel;     /* f32_pool index of texel (0,0).r */
+} hxr_bitmap;
+
+enum hxr_texture_type {
+	HXR_TEX_CHECKER = 0,     /* src/shading.h:56-67   color1, color2, scaling */
+	HXR_TEX_BITMAP = 1,      /* src/shading.h:69-85   bitmap, scaling */
+	HXR_TEX_FRESNEL = 2,     /* src/shading.h:179-187 ior */
+	HXR_TEX_BUMPTEX = 3,     /* src/shading.h:189-204 bitmap (already differentiated), strength, scaling */
+	HXR_TEX_BUMPS = 4        /* src/shading.h:217-227 strength (float in the reference) */
+};
+
+typedef struct hxr_texture {
+	int32_t type;
+	int32_t bitmap;
+	float color1[3], color2[3];
+	double scaling;
+	double strength;
+	double ior;
+} hxr_texture;
+
+enum hxr_shader_type {
+	HXR_SHADER_LAMBERT = 0,     /* src/shading.h:95-109  color, texture */
+	HXR_SHADER_PHONG = 1,       /* src/shading.h:111-123 + specular, exponent */
+	HXR_SHADER_REFLECTION = 2,  /* src/shading.h:125-145 color = reflColor, glossiness, num_samples */
+	HXR_SHADER_REFRACTION = 3,  /* src/shading.h:147-164 color = refrColor, ior */
+	HXR_SHADER_LAYERED = 4,     /* src/shading.h:166-177 first_layer, num_layers */
+	HXR_SHADER_CONST = 5        /* src/shading.h:206-214 color */
+};
+
+typedef struct hxr_shader {
+	int32_t type;
+	int32_t texture;
+	float color[3];
+	float specular[3];
+	float exponent;
+	float glossiness;
+	int32_t num_samples;
+	int32_t first_layer, num_layers;
+	int32_t pad_;
+	double ior;
+} hxr_shader;
+
+/* Layered::Layer (reference src/shading.h:167-171). */
+typedef struct hxr_layer {
+	int32_t shader;
+	int32_t texture;
+	float blend[3];
+} hxr_layer;
+
+enum hxr_light_type {
+	HXR_LIGHT_POINT = 0,     /* src/lights.h:79-96 */
+	HXR_LIGHT_RECT = 1       /* src/lights.h:98-121; area / scale_factor as left by beginFrame (src/lights.cpp:77-89) */
+};
+
+typedef struct hxr_light {
+	int32_t type;
+	int32_t x_subd, y_subd;
+	float color[3];
+	float power;
+	float scale_factor;
+	double pos[3];
+	double area;
+	hxr_transform T;
+} hxr_light;
+
+/* Node (reference src/node.h:31-47). Only nodes WITH a shader are listed (src/scene.cpp:558-565). */
+typedef struct hxr_node {
+	int32_t geometry, shader, bump;
+	int32_t pad_;
+	hxr_transform T;
+} hxr_node;
+
+/* Camera after beginFrame (reference src/camera.cpp:30-63): the frustum corner basis. */
+typedef struct hxr_camera {
+	double pos[3];
+	double top_left[3], top_right[3], bottom_left[3];
+	double up[3], right[3], front[3];
+	double aperture_size;       /* 2.5 / fNumber */
+	double focal_plane_dist;
+	double stereo_separation;
+	int32_t dof, num_samples, auto_focus, pad_;
+} hxr_camera;
+
+/* GlobalSettings (reference src/scene.h:244-269), the fields the path reads. */
+typedef struct hxr_settings {
+	float ambient[3];
+	float background[3];
+	int32_t max_trace_depth;
+	int32_t want_aa;
+	int32_t gi;
+	int32_t num_paths;
+	int32_t frame_width, frame_height;
+} hxr_settings;
+
+/* CubemapEnvironment (reference src/environment.h:49-73): sides in CubeOrder NEGX..POSZ. */
+typedef struct hxr_environment {
+	int32_t present;         /* scene.environment != NULL */
+	int32_t loaded;          /* Environment::loaded */
+	int32_t side_bitmap[6];
+} hxr_environment;
+
+typedef struct hxr_scene_desc {
+	uint32_t abi_version;    /* HXR_ABI_VERSION */
+	uint32_t reserved_;
+	hxr_settings settings;
+	hxr_camera camera;
+	hxr_environment environment;
+
+	const hxr_geometry* geometries;        int64_t num_geometries;
+	const hxr_mesh* meshes;                int64_t num_meshes;
+	const hxr_heightfield* heightfields;   int64_t num_heightfields;
+	const hxr_triangle* triangles;         int64_t num_triangles;
+	const hxr_kd_node* kd_nodes;           int64_t num_kd_nodes;
+	const int32_t* leaf_indices;           int64_t num_leaf_indices;
+	const hxr_bitmap* bitmaps;             int64_t num_bitmaps;
+	const hxr_texture* textures;           int64_t num_textures;
+	const hxr_shader* shaders;             int64_t num_shaders;
+	const hxr_layer* layers;               int64_t num_layers;
+	const hxr_light* lights;               int64_t num_lights;
+	const hxr_node* nodes;                 int64_t num_nodes;
+	const double* f64_pool;                int64_t f64_pool_size;   /* in doubles */
+	const float* f32_pool;                 int64_t f32_pool_size;   /* in floats */
+} hxr_scene_desc;
+
+/* ------------------------------------------------------------------ frame parameters */
+
+enum hxr_render_mode {
+	HXR_MODE_AUTO = 0,        /* what render() picks (src/main.cpp:416-426): MC if dof/gi, else 1 spp (+AA if wantAA) */
+	HXR_MODE_SINGLE = 1,      /* pass 1 of renderWithoutMonteCarlo only (src/main.cpp:273-314) */
+	HXR_MODE_ADAPTIVE_AA = 2, /* all three passes of renderWithoutMonteCarlo (src/main.cpp:253-345) */
+	HXR_MODE_MONTE_CARLO = 3  /* renderWithMonteCarlo (src/main.cpp:347-384) with `spp` rays per pixel */
+};
+
+enum hxr_output_layout {
+	HXR_LAYOUT_FRAME = 0,     /* out[y*row_stride + x*12]: the reference's vfb[y][x] (row stride 23040 B there) */
+	HXR_LAYOUT_TILES = 1      /* this rank's tiles back to back, each tile_size*tile_size*3 floats, row-major inside */
+};
+
+typedef struct hxr_frame_params {
+	int32_t width, height;    /* 0 = settings.frame_width / frame_height; at most 1920 (VFB_MAX_SIZE, src/constants.h:27) */
+	int32_t mode;             /* hxr_render_mode */
+	int32_t spp;              /* MONTE_CARLO: rays per pixel; 0 = max(dof ? camera.num_samples : 0, gi ? num_paths : 0) */
+	uint64_t rng_seed;        /* counter-based generator key; 5489 = std::mt19937's default seed, used as OUR default */
+	int32_t tile_size;        /* sharding granule in pixels (square); 0 = 64 like the reference's buckets (src/main.cpp:515) */
+	int32_t shard_rank;       /* this process renders tiles t with t % shard_count == shard_rank (row-major tile order) */
+	int32_t shard_count;      /* 0 or 1 = whole frame */
+	int32_t layout;           /* hxr_output_layout */
+	int32_t collect_counters; /* nonzero: run the instrumented kernel build and fill hxr_get_counters() */
+	int32_t reserved_[5];
+} hxr_frame_params;
+
+/* Work counters of the last frame (feeds the algorithmic-bytes formula). */
+typedef struct hxr_counters {
+	uint64_t camera_samples;
+	uint64_t raycasts;        /* TraceContext::raycast calls (src/main.cpp:63) */
+	uint64_t shadow_queries;  /* visible() calls (src/main.cpp:171) */
+	uint64_t node_tests;      /* Node::intersect calls (src/geometry.cpp:196) */
+	uint64_t bbox_tests;      /* BBox::testIntersect calls (src/bbox.h:94) */
+	uint64_t kd_visits;       /* kd nodes entered (src/mesh.cpp:221) */
+	uint64_t leaf_indices;    /* leaf list entries read */
+	uint64_t tri_tests;       /* Mesh::intersectTriangle calls (src/mesh.cpp:178) */
+	uint64_t mesh_hits;       /* accepted mesh hits whose attributes were interpolated */
+	uint64_t tex_bilinear;    /* Bitmap::getFilteredPixel from textures / bump maps */
+	uint64_t env_bilinear;    /* Bitmap::getFilteredPixel from the cubemap */
+	uint64_t hf_calls;        /* Heightfield::intersect calls */
+	uint64_t hf_highest;      /* getHighest reads */
+	uint64_t hf_height;       /* getHeight + maxH reads */
+	uint64_t hf_tri_tests;    /* intersectTriangleFast calls */
+	uint64_t hf_normals;      /* getNormal calls */
+	uint64_t aa_pixels;       /* pixels flagged by detectAApixels */
+	uint64_t reserved_[7];
+} hxr_counters;
+
+typedef struct hxr_scene hxr_scene;   /* opaque: the scene resident in HBM */
+
+/* Rectangle finished callback: maps to displayVFBRect(r, vfb) (reference src/main.cpp:312,340,379). */
+typedef void (*hxr_progress_cb)(void* user, int x0, int y0, int x1, int y1);
+
+/* ------------------------------------------------------------------ entry points */
+
+/* Number of gfx950 devices visible to this process (0 if none).  Never fails. */
+int hxr_device_count(void);
+
+/* Bind this process to one device (one process per GPU).  Replaces the reference's
+ * `threadPool = std::make_unique<ThreadPool>(numThreads)` (src/main.cpp:543-545). */
+int hxr_init(int device_id);
+
+/* Deep-copy a flattened scene into HBM (re-laid out for the kernels).  Caller keeps the host arrays.
+ * Replaces scene.beginRender()+beginFrame() as far as the render path is concerned (src/scene.cpp:754-762).
+ * Returns NULL on failure; hxr_last_error() says why. */
+hxr_scene* hxr_scene_create(const hxr_scene_desc* desc);
+
+/* Per-frame camera update (Camera::beginFrame, src/camera.cpp:30-63, after move/rotate). */
+int hxr_scene_update_camera(hxr_scene* scene, const hxr_camera* camera);
+
+/* Blocking frame render into a HOST buffer.  Replaces render() (src/main.cpp:416-426).
+ * `vfb` receives float RGB at byte offset y*row_stride_bytes + x*12 (pass &vfb[0][0], 23040 for the
+ * reference's global).  `cancel` may be NULL; when *cancel becomes nonzero the call returns
+ * HXR_CANCELLED at the next pass boundary (checkForUserExit, src/sdl.cpp:253).  `cb` may be NULL. */
+int hxr_render(hxr_scene* scene, const hxr_frame_params* params, float* vfb, size_t row_stride_bytes,
+               const volatile int* cancel, hxr_progress_cb cb, void* user);
+
+/* Asynchronous frame render into a DEVICE buffer on `hip_stream` (a hipStream_t, NULL = default
+ * stream).  Used by one-process-per-GPU sharded runs: each rank renders its tiles, the ranks' buffers
+ * are gathered with one RCCL gather.  `d_out` must hold hxr_output_bytes() bytes. */
+int hxr_render_device(hxr_scene* scene, const hxr_frame_params* params, float* d_out,
+                      size_t row_stride_bytes, void* hip_stream);
+
+/* Bytes hxr_render_device writes for these parameters (layout FRAME: height*row_stride_bytes). */
+size_t hxr_output_bytes(const hxr_scene* scene, const hxr_frame_params* params, size_t row_stride_bytes);
+
+/* Number of tiles this shard owns, and the pixel rectangle of its i-th tile. */
+int hxr_shard_tile_count(const hxr_scene* scene, const hxr_frame_params* params);
+int hxr_shard_tile_rect(const hxr_scene* scene, const hxr_frame_params* params, int i,
+                        int* x0, int* y0, int* x1, int* y1);
+
+/* Scatter tile-major shard buffers (as gathered from all ranks, rank-major) into a row-major frame.
+ * All pointers are DEVICE pointers; runs on `hip_stream`. */
+int hxr_assemble_frame(const hxr_scene* scene, const hxr_frame_params* params, const float* d_gathered,
+                       size_t per_rank_bytes, float* d_frame, size_t row_stride_bytes, void* hip_stream);
+
+/* float RGB -> 8-bit sRGB through the reference's 4097-entry table (src/sdl.cpp:404-419,
+ * src/color.h:36-47,84-90).  DEVICE pointers; `d_bgr` receives B,G,R bytes per pixel, rows top-down. */
+int hxr_quantize_srgb8(const float* d_frame, size_t row_stride_bytes, int width, int height,
+                       uint8_t* d_bgr, void* hip_stream);
+
+int hxr_get_counters(const hxr_scene* scene, hxr_counters* out);
+
+/* Milliseconds the dominant render kernel took in the last hxr_render / hxr_render_device call that
+ * has completed (HIP events on the launch stream); negative if unknown. */
+double hxr_last_kernel_ms(const hxr_scene* scene);
+
+void hxr_scene_destroy(hxr_scene* scene);
+
+/* Thread-local, never NULL. */
+const char* hxr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEXRAY_HIP_H */
