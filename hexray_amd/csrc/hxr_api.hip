@@ -1,0 +1,705 @@
+// libhexray_hip.so -- host side of the C ABI declared in include/hexray_hip.h.
+// Uploads the flattened scene into HBM in the kernels' layout (hxr_device_scene.h), launches the
+// render / AA-detect / assemble kernels on the caller's stream and times the render kernel with HIP
+// events.  One process drives one GPU.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "hexray_hip.h"
+#include "hxr_kernels.hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_device = -1;
+int g_num_cu = 256;
+
+void set_err(const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+			return HXR_E_HIP;                                                                      \
+		}                                                                                          \
+	} while (0)
+
+struct Arena {   // every device allocation of a scene, freed together
+	std::vector<void*> blocks;
+	template <class T>
+	int upload(const T* host, size_t n, const T** out)
+	{
+		*out = nullptr;
+		if (!n) return 0;
+		void* p = nullptr;
+		HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+		blocks.push_back(p);
+		HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+		*out = (const T*)p;
+		return 0;
+	}
+	int alloc(size_t bytes, void** out)
+	{
+		HIP_TRY(hipMalloc(out, bytes));
+		blocks.push_back(*out);
+		return 0;
+	}
+	void release()
+	{
+		for (void* p : blocks) (void)hipFree(p);
+		blocks.clear();
+	}
+};
+
+}  // namespace
+
+struct hxr_scene {
+	Arena arena;
+	HxrSceneDev host_view;          // device pointers inside, host copy of the header
+	HxrSceneDev* dev = nullptr;     // the same struct in HBM
+	hxr_settings settings;
+	hxr_camera camera;
+	// per-frame scratch, grown on demand
+	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
+	float* d_scratch = nullptr;     size_t scratch_bytes = 0;  // sharded-AA full frame
+	int32_t* d_aa_list = nullptr;   size_t aa_capacity = 0;
+	int32_t* d_extra = nullptr;     size_t extra_capacity = 0;
+	uint32_t* d_work = nullptr;     // [0] dispenser pass 1/MC, [1] dispenser pass 3, [2] aa count
+	unsigned long long* d_counters = nullptr;
+	uint8_t* d_lut = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool timed = false;
+	bool counters_valid = false;
+	uint64_t aa_pixels_host = 0;
+};
+
+namespace {
+
+// How many secondary rays one hit of `shader` can leave pending, and how many (shader, weight) pairs
+// its expansion can hold at once -- checked against the kernels' fixed per-lane stacks.
+void shader_fanout(const hxr_scene_desc* d, int si, int depth, int& rays, int& pending, bool& glossy, bool& cyclic)
+{
+	if (depth > 16) { cyclic = true; return; }
+	const hxr_shader& s = d->shaders[si];
+	if (s.type == HXR_SHADER_REFLECTION) { rays += 1; if (s.glossiness < 1.0f) glossy = true; }
+	else if (s.type == HXR_SHADER_REFRACTION) rays += 1;
+	else if (s.type == HXR_SHADER_LAYERED) {
+		pending += s.num_layers;
+		for (int i = 0; i < s.num_layers; i++) shader_fanout(d, d->layers[s.first_layer + i].shader, depth + 1, rays, pending, glossy, cyclic);
+	}
+}
+
+int validate(const hxr_scene_desc* d)
+{
+	if (!d || d->abi_version != HXR_ABI_VERSION) { set_err("bad descriptor / ABI version"); return HXR_E_INVALID; }
+	if (d->num_nodes < 0 || d->num_nodes > 4096) { set_err("bad node count"); return HXR_E_INVALID; }
+	for (int64_t i = 0; i < d->num_nodes; i++) {
+		const hxr_node& n = d->nodes[i];
+		if (n.geometry < 0 || n.geometry >= d->num_geometries || n.shader < 0 || n.shader >= d->num_shaders || n.bump >= d->num_textures) {
+			set_err("node %lld refers outside the tables", (long long)i);
+			return HXR_E_INVALID;
+		}
+		const hxr_geometry& g = d->geometries[n.geometry];
+		if (g.type == HXR_GEOM_CSG_UNION || g.type == HXR_GEOM_CSG_INTER || g.type == HXR_GEOM_CSG_DIFF) {
+			set_err("CSG geometry (node %lld) is not rendered by this build", (long long)i);
+			return HXR_E_UNSUPPORTED;
+		}
+		if (g.type == HXR_GEOM_MESH && (g.ref < 0 || g.ref >= d->num_meshes)) { set_err("bad mesh reference"); return HXR_E_INVALID; }
+		if (g.type == HXR_GEOM_HEIGHTFIELD && (g.ref < 0 || g.ref >= d->num_heightfields)) { set_err("bad heightfield reference"); return HXR_E_INVALID; }
+		int rays = 0, pending = 1;
+		bool glossy = false, cyclic = false;
+		shader_fanout(d, n.shader, 0, rays, pending, glossy, cyclic);
+		if (cyclic) { set_err("Layered shaders of node %lld refer to themselves", (long long)i); return HXR_E_UNSUPPORTED; }
+		if (glossy) { set_err("glossy Reflection (node %lld) is not rendered by this build", (long long)i); return HXR_E_UNSUPPORTED; }
+		if (pending > HXR_SHADER_STACK) { set_err("Layered shader of node %lld is wider than %d entries", (long long)i, HXR_SHADER_STACK); return HXR_E_UNSUPPORTED; }
+		long need = rays <= 1 ? 2 : (long)(d->settings.max_trace_depth + 1) * (rays - 1) + 2;
+		if (need > HXR_RAY_STACK) {
+			set_err("node %lld can leave %ld secondary rays pending (limit %d)", (long long)i, need, HXR_RAY_STACK);
+			return HXR_E_UNSUPPORTED;
+		}
+	}
+	for (int64_t i = 0; i < d->num_shaders; i++) {
+		const hxr_shader& s = d->shaders[i];
+		if (s.texture >= d->num_textures) { set_err("bad texture reference"); return HXR_E_INVALID; }
+		if (s.type == HXR_SHADER_LAYERED)
+			for (int k = 0; k < s.num_layers; k++) {
+				const hxr_layer& L = d->layers[s.first_layer + k];
+				if (L.shader < 0 || L.shader >= d->num_shaders || L.texture >= d->num_textures) { set_err("bad layer reference"); return HXR_E_INVALID; }
+			}
+	}
+	for (int64_t i = 0; i < d->num_textures; i++) {
+		const hxr_texture& t = d->textures[i];
+		if ((t.type == HXR_TEX_BITMAP || t.type == HXR_TEX_BUMPTEX) && (t.bitmap < 0 || t.bitmap >= d->num_bitmaps)) { set_err("bad bitmap reference"); return HXR_E_INVALID; }
+	}
+	return 0;
+}
+
+// kd records: parent link + the bound each node overrides (see hxr_device_scene.h)
+void build_kd_records(const hxr_scene_desc* d, const hxr_mesh& m, std::vector<HxrKdRec>& recs, std::vector<HxrTriHot>& hot, std::vector<int32_t>& ids)
+{
+	const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
+	const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
+	const hxr_triangle* tris = d->triangles + m.first_triangle;
+	const double* verts = d->f64_pool + m.first_vertex * 3;
+	auto push_hot = [&](int ti) {
+		const hxr_triangle& t = tris[ti];
+		HxrTriHot h;
+		for (int c = 0; c < 3; c++) {
+			h.A[c] = verts[(size_t)t.v[0] * 3 + c];
+			h.AB[c] = t.AB[c];
+			h.AC[c] = t.AC[c];
+			h.N[c] = t.ABcrossAC[c];
+		}
+		hot.push_back(h);
+		ids.push_back(ti);
+	};
+	if (!m.has_kd || m.num_kd_nodes == 0) {
+		for (int64_t i = 0; i < m.num_triangles; i++) push_hot((int)i);
+		return;
+	}
+	recs.resize((size_t)m.num_kd_nodes);
+	struct Item { int node; double lo[3], hi[3]; };
+	std::vector<Item> todo;
+	Item root;
+	root.node = 0;
+	for (int c = 0; c < 3; c++) { root.lo[c] = m.bbox_min[c]; root.hi[c] = m.bbox_max[c]; }
+	recs[0].saved = 0;
+	todo.push_back(root);
+	while (!todo.empty()) {
+		Item it = todo.back();
+		todo.pop_back();
+		const hxr_kd_node& n = nodes[it.node];
+		HxrKdRec& r = recs[(size_t)it.node];
+		r.split = n.split;
+		r.parent = n.parent;
+		r.axis = n.axis;
+		if (n.axis == HXR_KD_LEAF) {
+			r.first = (int32_t)hot.size();
+			r.count = n.count;
+			for (int i = 0; i < n.count; i++) push_hot(leaf_idx[n.first + i]);
+			continue;
+		}
+		r.first = n.first;
+		r.count = 0;
+		Item L = it, R = it;
+		L.node = n.first;
+		R.node = n.first + 1;
+		recs[(size_t)L.node].saved = it.hi[n.axis];   // the left child's box replaces hi[axis] by the split
+		recs[(size_t)R.node].saved = it.lo[n.axis];   // the right child's box replaces lo[axis]
+		L.hi[n.axis] = n.split;
+		R.lo[n.axis] = n.split;
+		todo.push_back(R);
+		todo.push_back(L);   // left first, so hot records follow the builder's leaf order
+	}
+}
+
+int ensure(void** p, size_t* have, size_t need)
+{
+	if (*have >= need && *p) return 0;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr;
+	*have = 0;
+	HIP_TRY(hipMalloc(p, need));
+	*have = need;
+	return 0;
+}
+
+struct Plan {   // resolved frame parameters
+	int W, H, mode, spp, tile, tiles_x, tiles_y, rank, count, ntiles, layout;
+	uint64_t seed;
+};
+
+int resolve(const hxr_scene* s, const hxr_frame_params* fp, Plan& p)
+{
+	if (!s || !fp) { set_err("null scene / params"); return HXR_E_INVALID; }
+	p.W = fp->width > 0 ? fp->width : s->settings.frame_width;
+	p.H = fp->height > 0 ? fp->height : s->settings.frame_height;
+	if (p.W <= 0 || p.H <= 0 || p.W > 1920 || p.H > 1920) { set_err("frame %dx%d outside 1..1920 (VFB_MAX_SIZE)", p.W, p.H); return HXR_E_INVALID; }
+	p.mode = fp->mode;
+	p.spp = fp->spp;
+	int rpp = 0;   // render(): raysPerPixel = max(dof ? numSamples : 0, gi ? numPaths : 0)  (src/main.cpp:421-424)
+	if (s->camera.dof) rpp = s->camera.num_samples;
+	if (s->settings.gi) rpp = std::max(rpp, s->settings.num_paths);
+	if (p.mode == HXR_MODE_AUTO) {
+		if (rpp > 0) { p.mode = HXR_MODE_MONTE_CARLO; if (p.spp <= 0) p.spp = rpp; }
+		else p.mode = s->settings.want_aa ? HXR_MODE_ADAPTIVE_AA : HXR_MODE_SINGLE;
+	}
+	if (p.mode == HXR_MODE_MONTE_CARLO) { if (p.spp <= 0) p.spp = rpp > 0 ? rpp : 1; }
+	else if (p.mode == HXR_MODE_SINGLE || p.mode == HXR_MODE_ADAPTIVE_AA) p.spp = 1;
+	else { set_err("unknown render mode %d", p.mode); return HXR_E_INVALID; }
+	if (p.spp > 65536) { set_err("spp too large"); return HXR_E_INVALID; }
+	p.tile = fp->tile_size > 0 ? fp->tile_size : 64;
+	if (p.tile % 8 || p.tile > 1024) { set_err("tile_size must be a multiple of 8"); return HXR_E_INVALID; }
+	p.tiles_x = (p.W - 1) / p.tile + 1;
+	p.tiles_y = (p.H - 1) / p.tile + 1;
+	p.count = fp->shard_count > 1 ? fp->shard_count : 1;
+	p.rank = fp->shard_count > 1 ? fp->shard_rank : 0;
+	if (p.rank < 0 || p.rank >= p.count) { set_err("shard_rank outside shard_count"); return HXR_E_INVALID; }
+	int total = p.tiles_x * p.tiles_y;
+	p.ntiles = total > p.rank ? (total - p.rank + p.count - 1) / p.count : 0;
+	p.layout = fp->layout;
+	if (p.layout != HXR_LAYOUT_FRAME && p.layout != HXR_LAYOUT_TILES) { set_err("unknown layout"); return HXR_E_INVALID; }
+	p.seed = fp->rng_seed;
+	return 0;
+}
+
+void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
+{
+	memset(&L, 0, sizeof L);
+	L.W = p.W; L.H = p.H;
+	L.seed = p.seed;
+	L.tile_size = p.tile; L.tiles_x = p.tiles_x; L.tiles_y = p.tiles_y;
+	L.shard_rank = p.rank; L.shard_count = p.count; L.num_shard_tiles = p.ntiles;
+	L.aa_count = (const int32_t*)(s->d_work + 2);
+}
+
+int grid_for(uint32_t chunks)
+{
+	// persistent waves: enough blocks to fill every CU several times over, never more than the work
+	uint32_t blocks = (uint32_t)g_num_cu * 8u;
+	uint32_t need = (chunks + (HXR_BLOCK / 64) - 1) / (HXR_BLOCK / 64);
+	return (int)std::max(1u, std::min(blocks, need));
+}
+
+int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, bool timed)
+{
+	if (timed) HIP_TRY(hipEventRecord(s->ev0, st));
+	if (L.num_chunks > 0) {
+		int grid = grid_for(L.num_chunks);
+		if (counters) hipLaunchKernelGGL(hxr_render_kernel<true>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, L);
+		else hipLaunchKernelGGL(hxr_render_kernel<false>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, L);
+		HIP_TRY(hipGetLastError());
+	}
+	if (timed) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
+	return 0;
+}
+
+// pixels just outside this shard's tiles whose pass-1 colour detectAApixels needs
+void halo_pixels(const Plan& p, std::vector<int32_t>& out)
+{
+	out.clear();
+	if (p.count <= 1) return;
+	std::vector<uint8_t> mark((size_t)p.W * p.H, 0);
+	auto own = [&](int x, int y) { return ((y / p.tile) * p.tiles_x + x / p.tile) % p.count == p.rank; };
+	for (int i = 0; i < p.ntiles; i++) {
+		int t = i * p.count + p.rank;
+		int x0 = (t % p.tiles_x) * p.tile, y0 = (t / p.tiles_x) * p.tile;
+		int x1 = std::min(x0 + p.tile, p.W), y1 = std::min(y0 + p.tile, p.H);
+		for (int y = y0 - 1; y <= y1; y++)
+			for (int x = x0 - 1; x <= x1; x++) {
+				if (x < 0 || y < 0 || x >= p.W || y >= p.H) continue;
+				if (x >= x0 && x < x1 && y >= y0 && y < y1) continue;
+				if (own(x, y) || mark[(size_t)y * p.W + x]) continue;
+				mark[(size_t)y * p.W + x] = 1;
+				out.push_back(y * p.W + x);
+			}
+	}
+}
+
+int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, size_t stride, hipStream_t st)
+{
+	Plan p;
+	int rc = resolve(s, fp, p);
+	if (rc) return rc;
+	if (p.layout == HXR_LAYOUT_FRAME && stride < (size_t)p.W * 12) { set_err("row stride smaller than a row"); return HXR_E_INVALID; }
+	const bool counters = fp->collect_counters != 0;
+	HIP_TRY(hipMemsetAsync(s->d_work, 0, 4 * sizeof(uint32_t), st));
+	if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
+	s->counters_valid = counters;
+	s->timed = false;
+	HxrLaunch L;
+	fill_launch(s, p, L);
+	L.counters = counters ? s->d_counters : nullptr;
+	const uint32_t tile_pixels = (uint32_t)p.ntiles * (uint32_t)(p.tile * p.tile);
+
+	if (p.mode == HXR_MODE_MONTE_CARLO || p.mode == HXR_MODE_SINGLE) {
+		L.mode = p.mode == HXR_MODE_MONTE_CARLO ? 1 : 0;
+		L.spp = p.spp;
+		L.pixels_per_chunk = p.spp <= 64 ? 64 / p.spp : 1;
+		L.num_chunks = (tile_pixels + (uint32_t)L.pixels_per_chunk - 1) / (uint32_t)L.pixels_per_chunk;
+		L.out = d_out;
+		L.out_stride = stride;
+		L.out_tiles = p.layout == HXR_LAYOUT_TILES;
+		L.work_counter = s->d_work;
+		return launch_render(s, L, counters, st, true);
+	}
+
+	// adaptive AA: pass 1 -> detect -> pass 3 (src/main.cpp:253-345)
+	const bool direct = p.count == 1 && p.layout == HXR_LAYOUT_FRAME;   // render straight into the caller's frame
+	float* frame = d_out;
+	size_t fstride = stride;
+	std::vector<int32_t> halo;
+	if (!direct) {
+		fstride = (size_t)p.W * 12;
+		rc = ensure((void**)&s->d_scratch, &s->scratch_bytes, fstride * p.H);
+		if (rc) return rc;
+		frame = s->d_scratch;
+		halo_pixels(p, halo);
+		if (!halo.empty()) {
+			size_t cap = s->extra_capacity * sizeof(int32_t);
+			rc = ensure((void**)&s->d_extra, &cap, halo.size() * sizeof(int32_t));
+			if (rc) return rc;
+			s->extra_capacity = cap / sizeof(int32_t);
+			HIP_TRY(hipMemcpyAsync(s->d_extra, halo.data(), halo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+			HIP_TRY(hipStreamSynchronize(st));   // `halo` is a local
+		}
+	}
+	{
+		size_t cap = s->aa_capacity * sizeof(int32_t);
+		rc = ensure((void**)&s->d_aa_list, &cap, ((size_t)tile_pixels + 64) * sizeof(int32_t));
+		if (rc) return rc;
+		s->aa_capacity = cap / sizeof(int32_t);
+	}
+	L.mode = 0;
+	L.spp = 1;
+	L.pixels_per_chunk = 64;
+	L.num_extra_pixels = (int32_t)halo.size();
+	L.extra_pixels = s->d_extra;
+	L.num_chunks = (tile_pixels + (uint32_t)halo.size() + 63u) / 64u;
+	L.out = frame;
+	L.out_stride = fstride;
+	L.out_tiles = 0;
+	L.work_counter = s->d_work;
+	rc = launch_render(s, L, counters, st, true);
+	if (rc) return rc;
+	if (tile_pixels) {
+		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)g_num_cu * 8u);
+		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 2));
+		HIP_TRY(hipGetLastError());
+	}
+	// pass 3: the flagged-pixel count stays on the device; launch enough waves for the worst case and let them drain
+	HxrLaunch L3 = L;
+	L3.mode = 2;
+	L3.spp = 4;
+	L3.pixels_per_chunk = 16;
+	L3.num_extra_pixels = 0;
+	L3.aa_list = s->d_aa_list;
+	L3.num_chunks = (tile_pixels + 15u) / 16u;
+	L3.work_counter = s->d_work + 1;
+	rc = launch_render(s, L3, counters, st, false);
+	if (rc) return rc;
+	if (!direct) {
+		if (p.layout == HXR_LAYOUT_TILES) {
+			if (tile_pixels) {
+				int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, 2048u);
+				hipLaunchKernelGGL(hxr_extract_tiles_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, d_out);
+				HIP_TRY(hipGetLastError());
+			}
+		} else {
+			HIP_TRY(hipMemcpy2DAsync(d_out, stride, frame, fstride, (size_t)p.W * 12, p.H, hipMemcpyDeviceToDevice, st));
+		}
+	}
+	return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hxr_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int hxr_init(int device_id)
+{
+	int n = hxr_device_count();
+	if (n <= 0) { set_err("no HIP device visible"); return HXR_E_NO_DEVICE; }
+	if (device_id < 0 || device_id >= n) { set_err("device %d outside 0..%d", device_id, n - 1); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(device_id));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+	g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	g_device = device_id;
+	return 0;
+}
+
+hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
+{
+	if (g_device < 0) { set_err("hxr_init has not been called"); return nullptr; }
+	if (validate(d)) return nullptr;
+	hxr_scene* s = new hxr_scene;
+	auto fail = [&]() -> hxr_scene* { hxr_scene_destroy(s); return nullptr; };
+	HxrSceneDev& V = s->host_view;
+	memset(&V, 0, sizeof V);
+	s->settings = V.settings = d->settings;
+	s->camera = V.camera = d->camera;
+	V.environment = d->environment;
+	V.num_nodes = (int32_t)d->num_nodes;
+	V.num_lights = (int32_t)d->num_lights;
+	V.num_shaders = (int32_t)d->num_shaders;
+	V.num_textures = (int32_t)d->num_textures;
+
+	const double* d_f64 = nullptr;
+	const float* d_f32 = nullptr;
+	const hxr_triangle* d_tris = nullptr;
+	if (s->arena.upload(d->f64_pool, (size_t)d->f64_pool_size, &d_f64)) return fail();
+	if (s->arena.upload(d->f32_pool, (size_t)d->f32_pool_size, &d_f32)) return fail();
+	if (s->arena.upload(d->triangles, (size_t)d->num_triangles, &d_tris)) return fail();
+
+	std::vector<HxrMeshDev> meshes((size_t)d->num_meshes);
+	for (int64_t i = 0; i < d->num_meshes; i++) {
+		const hxr_mesh& m = d->meshes[i];
+		HxrMeshDev& o = meshes[(size_t)i];
+		memset(&o, 0, sizeof o);
+		memcpy(o.bbox_min, m.bbox_min, sizeof o.bbox_min);
+		memcpy(o.bbox_max, m.bbox_max, sizeof o.bbox_max);
+		o.faceted = m.faceted;
+		o.backface_culling = m.backface_culling;
+		o.has_kd = m.has_kd && m.num_kd_nodes > 0;
+		o.num_triangles = (int32_t)m.num_triangles;
+		std::vector<HxrKdRec> recs;
+		std::vector<HxrTriHot> hot;
+		std::vector<int32_t> ids;
+		build_kd_records(d, m, recs, hot, ids);
+		if (s->arena.upload(recs.data(), recs.size(), &o.kd)) return fail();
+		if (s->arena.upload(hot.data(), hot.size(), &o.leaf_tris)) return fail();
+		if (s->arena.upload(ids.data(), ids.size(), &o.leaf_tri_ids)) return fail();
+		o.tris = d_tris + m.first_triangle;
+		o.vertices = d_f64 + m.first_vertex * 3;
+		o.normals = d_f64 + m.first_normal * 3;
+		o.uvs = d_f64 + m.first_uv * 3;
+	}
+	if (s->arena.upload(meshes.data(), meshes.size(), &V.meshes)) return fail();
+
+	std::vector<HxrHeightfieldDev> hfs((size_t)d->num_heightfields);
+	for (int64_t i = 0; i < d->num_heightfields; i++) {
+		const hxr_heightfield& h = d->heightfields[i];
+		HxrHeightfieldDev& o = hfs[(size_t)i];
+		memset(&o, 0, sizeof o);
+		o.W = h.W; o.H = h.H; o.max_k = h.max_k; o.use_optimization = h.use_optimization;
+		memcpy(o.bbox_min, h.bbox_min, sizeof o.bbox_min);
+		memcpy(o.bbox_max, h.bbox_max, sizeof o.bbox_max);
+		o.heights = d_f32 + h.first_height;
+		o.max_h = d_f32 + h.first_maxh;
+		o.high_map = d_f32 + h.first_highmap;
+		o.normals = d_f64 + h.first_normal * 3;
+	}
+	if (s->arena.upload(hfs.data(), hfs.size(), &V.heightfields)) return fail();
+
+	std::vector<HxrBitmapDev> bms((size_t)d->num_bitmaps);
+	for (int64_t i = 0; i < d->num_bitmaps; i++) {
+		bms[(size_t)i].width = d->bitmaps[i].width;
+		bms[(size_t)i].height = d->bitmaps[i].height;
+		bms[(size_t)i].texels = d_f32 + d->bitmaps[i].first_texel;
+	}
+	if (s->arena.upload(bms.data(), bms.size(), &V.bitmaps)) return fail();
+
+	std::vector<HxrNodeDev> nodes((size_t)d->num_nodes);
+	for (int64_t i = 0; i < d->num_nodes; i++) {
+		const hxr_node& n = d->nodes[i];
+		const hxr_geometry& g = d->geometries[n.geometry];
+		HxrNodeDev& o = nodes[(size_t)i];
+		memset(&o, 0, sizeof o);
+		o.T = n.T;
+		o.geom_type = g.type;
+		o.geom = n.geometry;
+		o.ref = g.ref;
+		o.shader = n.shader;
+		o.bump = n.bump;
+		memcpy(o.p, g.p, sizeof o.p);
+	}
+	if (s->arena.upload(nodes.data(), nodes.size(), &V.nodes)) return fail();
+	if (s->arena.upload(d->geometries, (size_t)d->num_geometries, &V.geometries)) return fail();
+	if (s->arena.upload(d->textures, (size_t)d->num_textures, &V.textures)) return fail();
+	if (s->arena.upload(d->shaders, (size_t)d->num_shaders, &V.shaders)) return fail();
+	if (s->arena.upload(d->layers, (size_t)d->num_layers, &V.layers)) return fail();
+	if (s->arena.upload(d->lights, (size_t)d->num_lights, &V.lights)) return fail();
+
+	const HxrSceneDev* dv = nullptr;
+	if (s->arena.upload(&V, 1, &dv)) return fail();
+	s->dev = const_cast<HxrSceneDev*>(dv);
+	void* p = nullptr;
+	if (s->arena.alloc(4 * sizeof(uint32_t), &p)) return fail();
+	s->d_work = (uint32_t*)p;
+	if (s->arena.alloc(sizeof(hxr_counters), &p)) return fail();
+	s->d_counters = (unsigned long long*)p;
+	// sRGB table, built with the same expression as Color::init_sRGB_cache (src/sdl.cpp:406-412, src/color.h:36-47)
+	uint8_t lut[4097];
+	for (int i = 0; i <= 4096; i++) {
+		float x = i / 4096.0f;
+		unsigned v;
+		if (x <= 0) v = 0;
+		else if (x >= 1) v = 255;
+		else {
+			x = (x <= 0.0031308f) ? x * 12.02f : (1.0f + 0.055f) * powf(x, 1.0f / 2.4f) - 0.055f;
+			v = (unsigned)(int)floorf(x * 255.0f + 0.5f);
+		}
+		lut[i] = (uint8_t)v;
+	}
+	const uint8_t* dl = nullptr;
+	if (s->arena.upload(lut, 4097, &dl)) return fail();
+	s->d_lut = const_cast<uint8_t*>(dl);
+	if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
+	return s;
+}
+
+int hxr_scene_update_camera(hxr_scene* s, const hxr_camera* cam)
+{
+	if (!s || !cam) { set_err("null argument"); return HXR_E_INVALID; }
+	s->camera = *cam;
+	s->host_view.camera = *cam;
+	HIP_TRY(hipMemcpy((char*)s->dev + offsetof(HxrSceneDev, camera), cam, sizeof *cam, hipMemcpyHostToDevice));
+	return 0;
+}
+
+size_t hxr_output_bytes(const hxr_scene* s, const hxr_frame_params* fp, size_t row_stride_bytes)
+{
+	Plan p;
+	if (resolve(s, fp, p)) return 0;
+	if (p.layout == HXR_LAYOUT_TILES) return (size_t)p.ntiles * p.tile * p.tile * 12;
+	return (size_t)p.H * row_stride_bytes;
+}
+
+int hxr_shard_tile_count(const hxr_scene* s, const hxr_frame_params* fp)
+{
+	Plan p;
+	int rc = resolve(s, fp, p);
+	return rc ? rc : p.ntiles;
+}
+
+int hxr_shard_tile_rect(const hxr_scene* s, const hxr_frame_params* fp, int i, int* x0, int* y0, int* x1, int* y1)
+{
+	Plan p;
+	int rc = resolve(s, fp, p);
+	if (rc) return rc;
+	if (i < 0 || i >= p.ntiles) { set_err("tile index outside the shard"); return HXR_E_INVALID; }
+	int t = i * p.count + p.rank;
+	*x0 = (t % p.tiles_x) * p.tile;
+	*y0 = (t / p.tiles_x) * p.tile;
+	*x1 = std::min(*x0 + p.tile, p.W);
+	*y1 = std::min(*y0 + p.tile, p.H);
+	return 0;
+}
+
+int hxr_render_device(hxr_scene* s, const hxr_frame_params* fp, float* d_out, size_t row_stride_bytes, void* hip_stream)
+{
+	if (!s || !fp || !d_out) { set_err("null argument"); return HXR_E_INVALID; }
+	return render_on_stream(s, fp, d_out, row_stride_bytes, (hipStream_t)hip_stream);
+}
+
+int hxr_render(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_stride_bytes, const volatile int* cancel,
+               hxr_progress_cb cb, void* user)
+{
+	if (!s || !fp || !vfb) { set_err("null argument"); return HXR_E_INVALID; }
+	Plan p;
+	int rc = resolve(s, fp, p);
+	if (rc) return rc;
+	if (p.layout != HXR_LAYOUT_FRAME) { set_err("hxr_render writes FRAME layout only"); return HXR_E_INVALID; }
+	if (cancel && *cancel) return HXR_CANCELLED;
+	size_t dstride = (size_t)p.W * 12;
+	rc = ensure((void**)&s->d_frame, &s->frame_bytes, dstride * p.H);
+	if (rc) return rc;
+	if (p.count > 1) HIP_TRY(hipMemsetAsync(s->d_frame, 0, dstride * p.H, nullptr));
+	rc = render_on_stream(s, fp, s->d_frame, dstride, nullptr);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, s->d_frame, dstride, dstride, p.H, hipMemcpyDeviceToHost));
+	if (cancel && *cancel) return HXR_CANCELLED;
+	if (cb)
+		for (int i = 0; i < p.ntiles; i++) {
+			int x0, y0, x1, y1;
+			hxr_shard_tile_rect(s, fp, i, &x0, &y0, &x1, &y1);
+			cb(user, x0, y0, x1, y1);
+		}
+	return 0;
+}
+
+int hxr_assemble_frame(const hxr_scene* s, const hxr_frame_params* fp, const float* d_gathered, size_t per_rank_bytes, float* d_frame,
+                       size_t row_stride_bytes, void* hip_stream)
+{
+	Plan p;
+	int rc = resolve(s, fp, p);
+	if (rc) return rc;
+	if (!d_gathered || !d_frame) { set_err("null argument"); return HXR_E_INVALID; }
+	size_t total = (size_t)p.tiles_x * p.tiles_y * p.tile * p.tile;
+	int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+	hipLaunchKernelGGL(hxr_assemble_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_gathered, per_rank_bytes / sizeof(float), d_frame,
+	                   row_stride_bytes, p.W, p.H, p.tile, p.tiles_x, p.tiles_y, p.count);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int hxr_quantize_srgb8(const float* d_frame, size_t row_stride_bytes, int width, int height, uint8_t* d_bgr, void* hip_stream)
+{
+	if (!d_frame || !d_bgr || width <= 0 || height <= 0) { set_err("bad argument"); return HXR_E_INVALID; }
+	static uint8_t* lut = nullptr;   // process-wide copy of the table
+	if (!lut) {
+		uint8_t host[4097];
+		for (int i = 0; i <= 4096; i++) {
+			float x = i / 4096.0f;
+			unsigned v;
+			if (x <= 0) v = 0;
+			else if (x >= 1) v = 255;
+			else {
+				x = (x <= 0.0031308f) ? x * 12.02f : (1.0f + 0.055f) * powf(x, 1.0f / 2.4f) - 0.055f;
+				v = (unsigned)(int)floorf(x * 255.0f + 0.5f);
+			}
+			host[i] = (uint8_t)v;
+		}
+		HIP_TRY(hipMalloc((void**)&lut, sizeof host));
+		HIP_TRY(hipMemcpy(lut, host, sizeof host, hipMemcpyHostToDevice));
+	}
+	size_t total = (size_t)width * height;
+	int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+	hipLaunchKernelGGL(hxr_quantize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_frame, row_stride_bytes, width, height,
+	                   (const uint8_t*)lut, d_bgr);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int hxr_get_counters(const hxr_scene* s, hxr_counters* out)
+{
+	if (!s || !out) { set_err("null argument"); return HXR_E_INVALID; }
+	memset(out, 0, sizeof *out);
+	if (!s->counters_valid) { set_err("the last frame was rendered without collect_counters"); return HXR_E_INVALID; }
+	HIP_TRY(hipDeviceSynchronize());
+	unsigned long long raw[HC_NUM];
+	HIP_TRY(hipMemcpy(raw, s->d_counters, sizeof raw, hipMemcpyDeviceToHost));
+	uint64_t* o = (uint64_t*)out;
+	for (int i = 0; i < HC_NUM; i++) o[i] = raw[i];
+	uint32_t work[4];
+	HIP_TRY(hipMemcpy(work, s->d_work, sizeof work, hipMemcpyDeviceToHost));
+	out->aa_pixels = work[2];
+	return 0;
+}
+
+double hxr_last_kernel_ms(const hxr_scene* s)
+{
+	if (!s || !s->timed) return -1.0;
+	if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.0;
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.0;
+	return ms;
+}
+
+void hxr_scene_destroy(hxr_scene* s)
+{
+	if (!s) return;
+	(void)hipDeviceSynchronize();
+	s->arena.release();
+	if (s->d_frame) (void)hipFree(s->d_frame);
+	if (s->d_scratch) (void)hipFree(s->d_scratch);
+	if (s->d_aa_list) (void)hipFree(s->d_aa_list);
+	if (s->d_extra) (void)hipFree(s->d_extra);
+	if (s->ev0) (void)hipEventDestroy(s->ev0);
+	if (s->ev1) (void)hipEventDestroy(s->ev1);
+	delete s;
+}
+
+const char* hxr_last_error(void) { return g_err; }
+
+}  // extern "C"

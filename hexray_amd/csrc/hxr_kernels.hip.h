@@ -1,0 +1,1229 @@
+// HIP kernels of the render module (gfx950, wave64).  FP64 geometry, FP32 colour, no MFMA.
+//
+// Parallel decomposition: one camera sample per lane; a wavefront is a "ray packet" of 64 samples
+// taken from one 8x8 (Morton-ordered) pixel block, so the lanes of a wave walk the same nodes, the
+// same kd subtrees and the same shader.  Waves are persistent: each one pulls packet numbers from an
+// atomic dispenser until the frame is exhausted (the GPU analogue of the reference's atomic bucket
+// cursor, src/main.cpp:273-275).
+//
+// The reference's mutually recursive raytrace() <-> Shader::computeColor() (src/main.cpp:105-113,
+// src/shading.cpp:159-232,315-324) is flattened: because every shader is linear in the colours its
+// secondary rays return, a ray carries the product of the blend / reflectance factors on its path (its
+// "weight") and adds weight x leaf-colour into the sample's accumulator.  Pending secondary rays wait
+// on a small per-lane stack; Layered shaders are expanded through a per-lane shader work list.  The
+// float summation order therefore differs from the reference's (rounding-level, ~1e-7); every
+// geometric decision (which node, which triangle, which texel, which cell) follows the reference's
+// arithmetic expression by expression.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hxr_device_scene.h"
+#include "hxr_rng.hip.h"
+
+#define HXR_INF 1e99                  // src/constants.h:29
+#define HXR_PI 3.141592653589793238   // src/constants.h:28
+#define HXR_RF_GI_DIFFUSE 2u          // src/vector.h:176
+#define HXR_RAY_STACK 12              // pending secondary rays per lane (checked against the scene at create time)
+#define HXR_SHADER_STACK 8            // pending (shader, weight) pairs while a hit is being shaded
+#define HXR_DEV __device__ __forceinline__
+
+// counters (COUNT builds only); order = hxr_counters
+enum {
+	HC_SAMPLES, HC_RAYCASTS, HC_SHADOW, HC_NODE, HC_BBOX, HC_KD, HC_LEAFIDX, HC_TRI, HC_MESHHIT, HC_TEX, HC_ENV,
+	HC_HFCALL, HC_HFHIGH, HC_HFHEIGHT, HC_HFTRI, HC_HFNORM, HC_AA, HC_NUM
+};
+
+struct d3 { double x, y, z; };
+struct f3 { float x, y, z; };
+
+HXR_DEV d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
+HXR_DEV d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+HXR_DEV d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+HXR_DEV d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+HXR_DEV d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
+HXR_DEV d3 operator*(d3 a, double s) { return d3{a.x * s, a.y * s, a.z * s}; }
+HXR_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HXR_DEV d3 cross(d3 a, d3 b) { return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+HXR_DEV double len(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+HXR_DEV double len2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+HXR_DEV d3 unit(d3 a) { return a * (1.0 / len(a)); }                       // Vector::normalize, src/vector.h:79-83
+HXR_DEV d3 unit_lazy(d3 a)                                                 // normalize(), src/vector.h:160-165
+{
+	double l = len(a);
+	if (fabs(l - 1.0) < 1e-6) return a;
+	return a * (1 / l);
+}
+HXR_DEV double dist3(d3 a, d3 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z)); }
+HXR_DEV d3 faceforward(d3 ray, d3 n) { return dot(ray, n) < 0 ? n : -n; }  // src/vector.h:179-182
+HXR_DEV d3 reflect3(d3 i, d3 n) { return n * (2 * dot(-i, n)) + i; }       // src/vector.h:184-187
+HXR_DEV d3 mulm(d3 v, const double* m)                                     // v * M, src/matrix.h:53-60
+{
+	return d3{v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7], v.x * m[2] + v.y * m[5] + v.z * m[8]};
+}
+HXR_DEV double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+HXR_DEV f3 mkf(float x, float y, float z) { return f3{x, y, z}; }
+HXR_DEV f3 ldf(const float* p) { return f3{p[0], p[1], p[2]}; }
+HXR_DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+HXR_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+HXR_DEV f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+HXR_DEV f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+HXR_DEV f3 fdiv(f3 a, float d)                                             // Color / float, src/color.h:195-200
+{
+	if (d == 1) return a;
+	float m = 1.0f / d;
+	return f3{a.x * m, a.y * m, a.z * m};
+}
+HXR_DEV float intensity(f3 a) { return (a.x + a.y + a.z) / 3; }
+HXR_DEV bool is_zero(f3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+
+template <bool COUNT>
+struct Tally {
+	uint32_t c[COUNT ? HC_NUM : 1];
+	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; }
+	HXR_DEV void add(int which, uint32_t n = 1) { if (COUNT) c[which] += n; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// boxes
+// ------------------------------------------------------------------------------------------------
+struct Box { d3 lo, hi; };
+
+HXR_DEV bool box_holds(const Box& b, d3 p)   // BBox::inside, src/bbox.h:78-85
+{
+	return b.lo.x - 1e-6 <= p.x && p.x <= b.hi.x + 1e-6 && b.lo.y - 1e-6 <= p.y && p.y <= b.hi.y + 1e-6 &&
+	       b.lo.z - 1e-6 <= p.z && p.z <= b.hi.z + 1e-6;
+}
+
+// one axis of BBox::testIntersect (src/bbox.h:96-139).  0 = keep going, 1 = hit, -1 = miss
+HXR_DEV int box_axis(double oa, double da, double ia, double loa, double hia, double ou, double du, double lou, double hiu,
+                     double ov, double dv, double lov, double hiv)
+{
+	if ((da < 0 && oa < loa) || (da > 0 && oa > hia)) return -1;
+	if (fabs(da) < 1e-9) return 0;
+	double t = (loa - oa) * ia;
+	if (t < 0) return 0;   // near wall behind the origin: the far wall of this axis is skipped as well
+	double pu = ou + du * t;
+	if (lou <= pu && pu <= hiu) {
+		double pv = ov + dv * t;
+		if (lov <= pv && pv <= hiv) return 1;
+	}
+	t = (hia - oa) * ia;
+	if (t < 0) return 0;
+	pu = ou + du * t;
+	if (lou <= pu && pu <= hiu) {
+		double pv = ov + dv * t;
+		if (lov <= pv && pv <= hiv) return 1;
+	}
+	return 0;
+}
+
+// BBox::testIntersect; `inv` = (1/d.x, 1/d.y, 1/d.z), the reference's per-call `mul` hoisted out
+HXR_DEV bool box_hit(const Box& b, d3 o, d3 d, d3 inv)
+{
+	if (box_holds(b, o)) return true;
+	int r = box_axis(o.x, d.x, inv.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y, o.z, d.z, b.lo.z, b.hi.z);
+	if (r) return r > 0;
+	r = box_axis(o.y, d.y, inv.y, b.lo.y, b.hi.y, o.x, d.x, b.lo.x, b.hi.x, o.z, d.z, b.lo.z, b.hi.z);
+	if (r) return r > 0;
+	r = box_axis(o.z, d.z, inv.z, b.lo.z, b.hi.z, o.x, d.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y);
+	return r > 0;
+}
+
+// one axis of BBox::closestIntersectionPeriphery (src/bbox.h:145-167); false = the ray cannot hit the box
+HXR_DEV bool box_near_axis(double oa, double da, double loa, double hia, double ou, double du, double lou, double hiu, double ov,
+                           double dv, double lov, double hiv, double& best)
+{
+	if ((da < 0 && oa < loa) || (da > 0 && oa > hia)) return false;
+	if (fabs(da) < 1e-9) return true;
+	double mul = 1 / da;
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		double t = ((j ? hia : loa) - oa) * mul;
+		if (t < 0) continue;
+		double pu = ou + du * t;
+		if (lou <= pu && pu <= hiu) {
+			double pv = ov + dv * t;
+			if (lov <= pv && pv <= hiv) best = fmin(best, t);
+		}
+	}
+	return true;
+}
+
+HXR_DEV double box_nearest(const Box& b, d3 o, d3 d)   // BBox::closestIntersection, src/bbox.h:169-174
+{
+	if (box_holds(b, o)) return 0;
+	double best = HXR_INF;
+	if (!box_near_axis(o.x, d.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y, o.z, d.z, b.lo.z, b.hi.z, best)) return HXR_INF;
+	if (!box_near_axis(o.y, d.y, b.lo.y, b.hi.y, o.x, d.x, b.lo.x, b.hi.x, o.z, d.z, b.lo.z, b.hi.z, best)) return HXR_INF;
+	if (!box_near_axis(o.z, d.z, b.lo.z, b.hi.z, o.x, d.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y, best)) return HXR_INF;
+	return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry queries.  A query reports only what identifies the hit (distance along the object-space
+// ray, triangle + barycentrics, cube face); attributes are derived later for the winning node only.
+// ------------------------------------------------------------------------------------------------
+struct GeomHit {
+	double t;        // object-space distance (info.dist inside geometry code)
+	double l2, l3;   // mesh barycentrics
+	int tri;         // mesh triangle number / cube face (axis*2 + side)
+};
+
+HXR_DEV bool plane_query(const double* p, d3 o, d3 d, GeomHit& g)   // Plane::intersect, src/geometry.cpp:31-50
+{
+	double py = p[0], limit = p[1];
+	if (o.y > py && d.y >= 0) return false;
+	if (o.y < py && d.y <= 0) return false;
+	double t = (py - o.y) / d.y;
+	d3 ip = o + d * t;
+	if (fabs(ip.x) > limit || fabs(ip.z) > limit) return false;
+	g.t = t;
+	return true;
+}
+
+HXR_DEV bool sphere_query(const double* p, d3 o, d3 d, GeomHit& g)   // Sphere::intersect, src/geometry.cpp:52-85
+{
+	d3 O = ld3(p);
+	double R = p[3];
+	double A = len2(d);
+	d3 H = o - O;
+	double B = 2 * dot(d, H);
+	double C = len2(H) - R * R;
+	double D = B * B - 4 * A * C;
+	if (D < 0) return false;
+	double sD = sqrt(D);
+	double p1 = (-B - sD) / (2 * A), p2 = (-B + sD) / (2 * A);
+	if (p2 < 0) return false;
+	g.t = (p1 < 0) ? p2 : p1;
+	return true;
+}
+
+HXR_DEV bool cube_query(const double* p, d3 o, d3 d, GeomHit& g)   // Cube::intersect, src/geometry.cpp:87-147
+{
+	d3 O = ld3(p);
+	double half = p[3];
+	double best = HXR_INF;
+	int face = -1;
+#pragma unroll
+	for (int a = 0; a < 3; a++)
+#pragma unroll
+		for (int s = 0; s < 2; s++) {
+			double oa = comp(o, a), da = comp(d, a);
+			double target = comp(O, a) + (s ? half : -half);
+			if (fabs(da) < 1e-9) continue;
+			if (oa < target && da < 0) continue;
+			if (oa > target && da > 0) continue;
+			double t = (target - oa) / da;
+			if (!(t < best)) continue;
+			d3 ip = o + d * t;
+			if (!(ip.x > O.x - half - 1e-6 && ip.x < O.x + half + 1e-6)) continue;
+			if (!(ip.y > O.y - half - 1e-6 && ip.y < O.y + half + 1e-6)) continue;
+			if (!(ip.z > O.z - half - 1e-6 && ip.z < O.z + half + 1e-6)) continue;
+			best = t;
+			face = a * 2 + s;
+		}
+	g.t = best;
+	g.tri = face;
+	return face >= 0;
+}
+
+// Leaf of Mesh::intersectKD (src/mesh.cpp:223-232): every triangle is tested against the running
+// best distance; a hit counts for THIS leaf only if its point lies in the leaf's box.
+template <bool COUNT>
+HXR_DEV bool leaf_query(const HxrMeshDev& M, const HxrKdRec& leaf, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g, Tally<COUNT>& tl)
+{
+	bool found = false;
+	const HxrTriHot* T = M.leaf_tris + leaf.first;
+	for (int i = 0; i < leaf.count; i++) {
+		tl.add(HC_TRI);
+		tl.add(HC_LEAFIDX);
+		// Mesh::intersectTriangle, src/mesh.cpp:178-195
+		if (M.backface_culling) {
+			const hxr_triangle& ct = M.tris[M.leaf_tri_ids[leaf.first + i]];
+			if (dot(d, ld3(ct.gnormal)) > 0) continue;
+		}
+		d3 N = ld3(T[i].N);
+		double Dcr = dot(N, nd);
+		if (fabs(Dcr) < 1e-12) continue;
+		d3 H = o - ld3(T[i].A);
+		double rD = 1 / Dcr;
+		double gamma = dot(N, H) * rD;
+		if (gamma < 0 || gamma > g.t) continue;
+		double l2 = dot(cross(H, ld3(T[i].AC)), nd) * rD;
+		if (l2 < 0 || l2 > 1) continue;
+		double l3 = dot(cross(ld3(T[i].AB), H), nd) * rD;
+		if (l3 < 0 || l3 > 1) continue;
+		double l1 = 1 - (l2 + l3);
+		if (l1 < 0 || l1 > 1) continue;
+		g.t = gamma;
+		g.l2 = l2;
+		g.l3 = l3;
+		g.tri = M.leaf_tri_ids[leaf.first + i];
+		if (box_holds(box, o + d * gamma)) found = true;
+	}
+	return found;
+}
+
+HXR_DEV void set_lo(Box& b, int a, double v) { if (a == 0) b.lo.x = v; else if (a == 1) b.lo.y = v; else b.lo.z = v; }
+HXR_DEV void set_hi(Box& b, int a, double v) { if (a == 0) b.hi.x = v; else if (a == 1) b.hi.y = v; else b.hi.z = v; }
+
+// Mesh::intersect (src/mesh.cpp:247-263) with a STACKLESS walk of the reference's kd-tree.
+// The reference recursion visits, at a binary node, the child on the ray origin's side first, then the
+// other, each only if the ray touches the child's box (split() of the parent's box), and stops at the
+// first leaf that reports a hit (src/mesh.cpp:233-243).  Here the current box lives in registers: going
+// down overwrites one bound with the split position, coming up restores it from the child's record
+// (HxrKdRec::saved) and uses the parent link; `tried` counts the children of the current node that are done.
+template <bool COUNT>
+HXR_DEV bool mesh_query(const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, Tally<COUNT>& tl)
+{
+	Box box{ld3(M.bbox_min), ld3(M.bbox_max)};
+	d3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
+	tl.add(HC_BBOX);
+	if (!box_hit(box, o, d, inv)) return false;
+	d3 nd = -d;
+	g.t = HXR_INF;
+	g.tri = -1;
+	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
+		HxrKdRec all;
+		all.first = 0;
+		all.count = M.num_triangles;
+		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
+		leaf_query<COUNT>(M, all, everything, o, d, nd, g, tl);
+		return g.t < HXR_INF;
+	}
+	int n = 0;
+	HxrKdRec rec = M.kd[0];
+	tl.add(HC_KD);
+	if (rec.axis == HXR_KD_LEAF) return leaf_query<COUNT>(M, rec, box, o, d, nd, g, tl);
+	int tried = 0;
+	for (;;) {
+		if (tried == 2) {   // both children done: return to the parent
+			if (rec.parent < 0) return false;
+			int p = rec.parent;
+			HxrKdRec prec = M.kd[p];
+			bool was_left = (n == prec.first);
+			if (was_left) set_hi(box, prec.axis, rec.saved); else set_lo(box, prec.axis, rec.saved);
+			int first = comp(o, prec.axis) > prec.split ? 1 : 0;
+			tried = ((was_left ? 0 : 1) == first) ? 1 : 2;
+			n = p;
+			rec = prec;
+			continue;
+		}
+		int a = rec.axis;
+		int first = comp(o, a) > rec.split ? 1 : 0;
+		int c = tried == 0 ? first : 1 - first;
+		double old = c == 0 ? comp(box.hi, a) : comp(box.lo, a);
+		if (c == 0) set_hi(box, a, rec.split); else set_lo(box, a, rec.split);
+		tl.add(HC_BBOX);
+		if (box_hit(box, o, d, inv)) {
+			int child = rec.first + c;
+			HxrKdRec crec = M.kd[child];
+			tl.add(HC_KD);
+			if (crec.axis == HXR_KD_LEAF) {
+				if (leaf_query<COUNT>(M, crec, box, o, d, nd, g, tl)) return true;
+			} else {
+				n = child;
+				rec = crec;
+				tried = 0;
+				continue;
+			}
+		}
+		if (c == 0) set_hi(box, a, old); else set_lo(box, a, old);
+		tried++;
+	}
+}
+
+// intersectTriangleFast, src/mesh.cpp:131-170
+HXR_DEV bool tri_fast(d3 o, d3 d, d3 A, d3 B, d3 C, double& best)
+{
+	d3 AB = B - A, AC = C - A, D = -d, H = o - A;
+	d3 N = cross(AB, AC);
+	double Dcr = dot(N, D);
+	if (fabs(Dcr) < 1e-12) return false;
+	double l2 = dot(cross(H, AC), D) / Dcr;
+	double l3 = dot(cross(AB, H), D) / Dcr;
+	double gamma = dot(N, H) / Dcr;
+	if (gamma < 0 || gamma > best) return false;
+	if (l2 < 0 || l2 > 1 || l3 < 0 || l3 > 1 || l2 + l3 > 1) return false;
+	best = gamma;
+	return true;
+}
+
+HXR_DEV int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// Heightfield::intersect, src/heightfield.cpp:106-171
+template <bool COUNT>
+HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& g, Tally<COUNT>& tl)
+{
+	tl.add(HC_HFCALL);
+	Box box{ld3(F.bbox_min), ld3(F.bbox_max)};
+	d3 step = d * (1.0 / sqrt(d.x * d.x + d.z * d.z));
+	double dist = box_nearest(box, o, d);
+	d3 p = o + d * (dist + 1e-6);
+	double mx = 1.0 / d.x, mz = 1.0 / d.z;
+	while (box_holds(box, p)) {
+		int x0 = (int)floor(p.x), z0 = (int)floor(p.z);
+		if (x0 < 0 || x0 >= F.W || z0 < 0 || z0 >= F.H) break;
+		if (F.use_optimization) {
+			const float* hm = F.high_map + ((size_t)z0 * F.W + x0) * 16;   // (x0, z0) is in range here: no clamping needed
+			int k = 1;
+			while (k < F.max_k) {
+				tl.add(HC_HFHIGH);
+				if (!(p.y + step.y * (1 << k) > hm[k])) break;
+				k++;
+			}
+			k--;
+			if (k > 0) {
+				p = p + step * (double)(1 << k);
+				continue;
+			}
+		}
+		double lx = d.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
+		double lz = d.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
+		d3 pn = p + step * (fmin(lx, lz) + 1e-6);
+		tl.add(HC_HFHEIGHT);
+		if (fmin(p.y, pn.y) < F.max_h[(size_t)z0 * F.W + x0]) {
+			int x1 = clampi(x0 + 1, F.W - 1), z1 = clampi(z0 + 1, F.H - 1);   // getHeight clamps (src/heightfield.cpp:30-37)
+			tl.add(HC_HFHEIGHT, 4);
+			tl.add(HC_HFTRI, 2);
+			d3 A = mk3(x0, F.heights[(size_t)z0 * F.W + x0], z0);
+			d3 B = mk3(x0 + 1, F.heights[(size_t)z0 * F.W + x1], z0);
+			d3 C = mk3(x0 + 1, F.heights[(size_t)z1 * F.W + x1], z0 + 1);
+			d3 D = mk3(x0, F.heights[(size_t)z1 * F.W + x0], z0 + 1);
+			double best = HXR_INF;
+			bool b1 = tri_fast(o, d, A, B, D, best);
+			bool b2 = tri_fast(o, d, B, C, D, best);
+			if (b1 || b2) {
+				g.t = best;
+				return true;
+			}
+		}
+		p = pn;
+	}
+	return false;
+}
+
+// Heightfield::getNormal, src/heightfield.cpp:83-104
+HXR_DEV d3 heightfield_normal(const HxrHeightfieldDev& F, float x, float y)
+{
+	int x0 = (int)floorf(x), y0 = (int)floorf(y);
+	float p = x - x0, q = y - y0;
+	int x1 = min(F.W - 1, x0 + 1), y1 = min(F.H - 1, y0 + 1);
+	x0 = clampi(x0, F.W - 1);
+	y0 = clampi(y0, F.H - 1);
+	const double* n = F.normals;
+	d3 v = ld3(n + ((size_t)y0 * F.W + x0) * 3) * (double)((1 - p) * (1 - q)) + ld3(n + ((size_t)y0 * F.W + x1) * 3) * (double)(p * (1 - q)) +
+	       ld3(n + ((size_t)y1 * F.W + x0) * 3) * (double)((1 - p) * q) + ld3(n + ((size_t)y1 * F.W + x1) * 3) * (double)(p * q);
+	return unit(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// nodes
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, GeomHit& g, Tally<COUNT>& tl)
+{
+	switch (N.geom_type) {
+		case HXR_GEOM_PLANE: return plane_query(N.p, ol, dl, g);
+		case HXR_GEOM_SPHERE: return sphere_query(N.p, ol, dl, g);
+		case HXR_GEOM_CUBE: return cube_query(N.p, ol, dl, g);
+		case HXR_GEOM_MESH: return mesh_query<COUNT>(S.meshes[N.ref], ol, dl, g, tl);
+		case HXR_GEOM_HEIGHTFIELD: return heightfield_query<COUNT>(S.heightfields[N.ref], ol, dl, g, tl);
+		default: return false;   // CSG is rejected at scene creation (HXR_E_UNSUPPORTED)
+	}
+}
+
+// Node::intersect (src/geometry.cpp:196-208) up to the world-space distance
+template <bool COUNT>
+HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, Tally<COUNT>& tl)
+{
+	const HxrNodeDev& N = S.nodes[ni];
+	tl.add(HC_NODE);
+	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
+	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
+	if (!geometry_query<COUNT>(S, N, ol, dl, g, tl)) return false;
+	d3 ipw = mulm(ol + dl * g.t, N.T.m) + ld3(N.T.offset);
+	wdist = dist3(o, ipw);
+	return true;
+}
+
+// IntersectionInfo (src/geometry.h:33-40) of the accepted hit
+struct Surface {
+	double dist;
+	d3 ip, norm, dNdx, dNdy;
+	double u, v;
+};
+
+template <bool COUNT>
+HXR_DEV void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit& g, double wdist, Surface& sf, Tally<COUNT>& tl)
+{
+	const HxrNodeDev& N = S.nodes[ni];
+	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
+	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
+	d3 ip = ol + dl * g.t;
+	d3 n = mk3(0, 0, 0);
+	sf.dNdx = mk3(0, 0, 0);
+	sf.dNdy = mk3(0, 0, 0);
+	sf.u = sf.v = 0;
+	switch (N.geom_type) {
+		case HXR_GEOM_PLANE:
+			n = mk3(0, (ol.y > N.p[0]) ? 1 : -1, 0);
+			sf.u = ip.x;
+			sf.v = ip.z;
+			sf.dNdx = mk3(1, 0, 0);
+			sf.dNdy = mk3(0, 0, 1);
+			break;
+		case HXR_GEOM_SPHERE: {
+			n = unit(ip - ld3(N.p));
+			double v = asin(n.y), u = atan2(n.z, n.x);
+			v = -(v / HXR_PI + 0.5f);
+			u = u / (2 * HXR_PI) + 0.5f;
+			if (N.p[4] != 1) { u *= N.p[4]; v *= N.p[4]; }
+			sf.u = u;
+			sf.v = v;
+			break;
+		}
+		case HXR_GEOM_CUBE: {
+			int a = g.tri >> 1;
+			double sg = (g.tri & 1) ? 1 : -1;
+			n = mk3(a == 0 ? sg : 0, a == 1 ? sg : 0, a == 2 ? sg : 0);
+			if (a == 0) { sf.u = ip.y; sf.v = ip.z; }
+			else if (a == 1) { sf.u = ip.x; sf.v = ip.z; }
+			else { sf.u = ip.x; sf.v = ip.y; }
+			break;
+		}
+		case HXR_GEOM_MESH: {   // Mesh::intersectTriangle's attribute half, src/mesh.cpp:196-218
+			const HxrMeshDev& M = S.meshes[N.ref];
+			const hxr_triangle& t = M.tris[g.tri];
+			tl.add(HC_MESHHIT);
+			d3 tA = ld3(M.uvs + 3 * (size_t)t.t[0]), tB = ld3(M.uvs + 3 * (size_t)t.t[1]), tC = ld3(M.uvs + 3 * (size_t)t.t[2]);
+			d3 tc = tA + (tB - tA) * g.l2 + (tC - tA) * g.l3;
+			sf.u = tc.x;
+			sf.v = tc.y;
+			if (M.faceted) {
+				n = ld3(t.gnormal);
+			} else {
+				d3 nA = ld3(M.normals + 3 * (size_t)t.n[0]), nB = ld3(M.normals + 3 * (size_t)t.n[1]), nC = ld3(M.normals + 3 * (size_t)t.n[2]);
+				n = unit(nA + (nB - nA) * g.l2 + (nC - nA) * g.l3);
+			}
+			sf.dNdx = ld3(t.dNdx);
+			sf.dNdy = ld3(t.dNdy);
+			break;
+		}
+		case HXR_GEOM_HEIGHTFIELD: {
+			const HxrHeightfieldDev& F = S.heightfields[N.ref];
+			tl.add(HC_HFNORM);
+			n = heightfield_normal(F, (float)ip.x, (float)ip.z);
+			sf.u = ip.x / F.W;
+			sf.v = ip.z / F.H;
+			sf.dNdx = mk3(1, 0, 0);
+			sf.dNdy = mk3(0, 0, 1);
+			break;
+		}
+		default: break;
+	}
+	sf.ip = mulm(ip, N.T.m) + ld3(N.T.offset);
+	sf.norm = unit(mulm(n, N.T.tinv_m));
+	sf.dist = wdist;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights
+// ------------------------------------------------------------------------------------------------
+// RectLight::intersect, src/lights.cpp:50-75 (PointLight::intersect returns 0, :27-30)
+HXR_DEV int light_query(const hxr_light& L, d3 o, d3 d, double& dist)
+{
+	if (L.type != HXR_LIGHT_RECT) return 0;
+	d3 s = mulm(o - ld3(L.T.offset), L.T.inv_m);
+	d3 dl = unit_lazy(mulm(d, L.T.inv_m));
+	if (fabs(dl.y) < 1e-12) return 0;
+	double t = -(s.y / dl.y);
+	if (t < 0) return 0;
+	d3 p = s + dl * t;
+	if (fabs(p.x) < 0.5 && fabs(p.z) < 0.5) {
+		double w = len((mulm(p, L.T.m) + ld3(L.T.offset)) - o);
+		if (w < dist) {
+			dist = w;
+			return s.y < 0 ? +1 : -1;
+		}
+	}
+	return 0;
+}
+
+// Light::getNthSample: PointLight src/lights.h:88-92, RectLight src/lights.cpp:37-51 ((j1, j2) stand for its two randDouble())
+HXR_DEV void light_sample(const hxr_light& L, int idx, d3 shade_pos, double j1, double j2, d3& pos, f3& color)
+{
+	if (L.type == HXR_LIGHT_POINT) {
+		pos = ld3(L.pos);
+		color = ldf(L.color);
+		return;
+	}
+	double lx = ((idx % L.x_subd) + j1) / L.x_subd;
+	double ly = ((idx / L.x_subd) + j2) / L.y_subd;
+	pos = mulm(mk3(lx - 0.5, -1e-6, ly - 0.5), L.T.m) + ld3(L.T.offset);
+	d3 ls = mulm(shade_pos - ld3(L.T.offset), L.T.inv_m);
+	if (ls.y < 0) color = fdiv(ldf(L.color) * (float)(-ls.y), (float)len(ls));
+	else color = mkf(0, 0, 0);
+}
+
+HXR_DEV double light_solid_angle(const hxr_light& L, d3 p)   // RectLight::getSolidAngle, src/lights.cpp:91-102
+{
+	if (L.type != HXR_LIGHT_RECT) return 0;
+	d3 dir = unit_lazy(mulm(mk3(0, -1, 0), L.T.m));
+	d3 to_p = p - (mulm(mk3(0, 0, 0), L.T.m) + ld3(L.T.offset));
+	double c = dot(to_p, dir);
+	if (c < 0) return 0;
+	double dd = len(to_p);
+	c /= dd;
+	return L.area * c / ((1 + dd) * (1 + dd));
+}
+
+HXR_DEV int light_num_samples(const hxr_light& L) { return L.type == HXR_LIGHT_RECT ? L.x_subd * L.y_subd : 1; }
+
+// ------------------------------------------------------------------------------------------------
+// textures / environment
+// ------------------------------------------------------------------------------------------------
+HXR_DEV f3 bitmap_bilinear(const HxrBitmapDev& b, float x, float y)   // Bitmap::getFilteredPixel, src/bitmap.cpp:66-81
+{
+	int w = b.width, h = b.height;
+	if (w <= 0 || h <= 0 || x < 0 || x >= w || y < 0 || y >= h) return mkf(0, 0, 0);
+	int tx = (int)floorf(x), ty = (int)floorf(y);
+	if (tx < 0 || ty < 0) return mkf(0, 0, 0);
+	int tx1 = (tx + 1) % w, ty1 = (ty + 1) % h;
+	float p = x - tx, q = y - ty;
+	const float* t = b.texels;
+	return ldf(t + ((size_t)ty * w + tx) * 3) * ((1.0f - p) * (1.0f - q)) + ldf(t + ((size_t)ty * w + tx1) * 3) * (p * (1.0f - q)) +
+	       ldf(t + ((size_t)ty1 * w + tx) * 3) * ((1.0f - p) * q) + ldf(t + ((size_t)ty1 * w + tx1) * 3) * (p * q);
+}
+
+template <bool COUNT>
+HXR_DEV f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& sf, Tally<COUNT>& tl)
+{
+	const hxr_texture& t = S.textures[ti];
+	switch (t.type) {
+		case HXR_TEX_CHECKER: {   // src/shading.cpp:50-55
+			int u1 = (int)floor(sf.u / t.scaling), v1 = (int)floor(sf.v / t.scaling);
+			return ((u1 + v1) % 2 == 0) ? ldf(t.color1) : ldf(t.color2);
+		}
+		case HXR_TEX_BITMAP: {    // src/shading.cpp:147-157
+			const HxrBitmapDev& b = S.bitmaps[t.bitmap];
+			float u = (float)(sf.u / t.scaling), v = (float)(sf.v / t.scaling);
+			u -= floorf(u);
+			v -= floorf(v);
+			u *= b.width;
+			v *= b.height;
+			tl.add(HC_TEX);
+			return bitmap_bilinear(b, u, v);
+		}
+		case HXR_TEX_FRESNEL: {   // src/shading.cpp:326-343, float arithmetic
+			float eta = (float)t.ior;
+			float ndi = (float)dot(dir, sf.norm);
+			if (ndi > 0) eta = 1 / eta; else ndi = -ndi;
+			double ratio = (double)((1.0f - eta) / (1.0f + eta));
+			float f = (float)(ratio * ratio);
+			float x = 1 - ndi;
+			float fr = f + (1 - f) * powf(x, 5.0f);
+			return mkf(fr, fr, fr);
+		}
+		default: return mkf(0, 0, 0);
+	}
+}
+
+template <bool COUNT>
+HXR_DEV void texture_bump(const HxrSceneDev& S, int ti, Surface& sf, Tally<COUNT>& tl)
+{
+	const hxr_texture& t = S.textures[ti];
+	if (t.type == HXR_TEX_BUMPTEX) {   // BumpTexture::modifyNormal, src/shading.cpp:345-356
+		const HxrBitmapDev& b = S.bitmaps[t.bitmap];
+		float x = (float)fmod(sf.u * t.scaling * b.width, (double)b.width);
+		float y = (float)fmod(sf.v * t.scaling * b.height, (double)b.height);
+		tl.add(HC_TEX);
+		f3 bump = bitmap_bilinear(b, x, y);
+		float dx = (float)(bump.x * t.strength), dy = (float)(bump.y * t.strength);
+		sf.norm = unit(sf.norm + (sf.dNdx * (double)dx + sf.dNdy * (double)dy));
+	} else if (t.type == HXR_TEX_BUMPS) {   // Bumps::modifyNormal, src/shading.cpp:363-377
+		float strength = (float)t.strength;
+		if (strength > 0) {
+			const float fx[3] = {0.5f, 1.21f, 1.9f}, fz[3] = {0.4f, 1.13f, 1.81f}, amp[3] = {0.1f, 0.08f, 0.05f};
+			const float fm = 0.2f;
+			double dx = 0, dy = 0;
+#pragma unroll
+			for (int i = 0; i < 3; i++) {
+				dx += sin((fm * fx[i]) * sf.u) * amp[i] * strength;
+				dy += sin((fm * fz[i]) * sf.v) * amp[i] * strength;
+			}
+			sf.norm = unit(sf.norm + (sf.dNdx * dx + sf.dNdy * dy));
+		}
+	}
+}
+
+// CubemapEnvironment::getEnvironment, src/environment.cpp:54-81
+template <bool COUNT>
+HXR_DEV f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
+{
+	if (!S.environment.loaded) return mkf(0, 0, 0);
+	int dim = 0;
+	double big = fabs(dir.x);
+	if (fabs(dir.y) > big) { dim = 1; big = fabs(dir.y); }
+	if (fabs(dir.z) > big) dim = 2;
+	double lead = comp(dir, dim);
+	d3 s = dir * (1.0 / fabs(lead));
+	int face = (lead > 0 ? 3 : 0) + dim;
+	double fx, fy;
+	switch (face) {
+		case 0: fx = s.z; fy = -s.y; break;
+		case 1: fx = s.x; fy = -s.z; break;
+		case 2: fx = s.x; fy = s.y; break;
+		case 3: fx = -s.z; fy = -s.y; break;
+		case 4: fx = s.x; fy = s.z; break;
+		default: fx = s.x; fy = -s.y; break;
+	}
+	const HxrBitmapDev& b = S.bitmaps[S.environment.side_bitmap[face]];
+	tl.add(HC_ENV);
+	return bitmap_bilinear(b, (float)((fx + 1) * 0.5 * (b.width - 1)), (float)((fy + 1) * 0.5 * (b.height - 1)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene queries
+// ------------------------------------------------------------------------------------------------
+// visible(), src/main.cpp:171-190: any node closer than |AB|, or any light in between, blocks
+template <bool COUNT>
+HXR_DEV bool visible(const HxrSceneDev& S, d3 A, d3 B, Tally<COUNT>& tl)
+{
+	tl.add(HC_SHADOW);
+	double D = dist3(A, B);
+	d3 d = unit(B - A);
+	for (int ni = 0; ni < S.num_nodes; ni++) {
+		GeomHit g;
+		double w;
+		if (node_query<COUNT>(S, ni, A, d, g, w, tl) && w < D) return false;
+	}
+	for (int li = 0; li < S.num_lights; li++) {
+		double dd = D;
+		if (light_query(S.lights[li], A, d, dd)) return false;
+	}
+	return true;
+}
+
+struct RayItem {
+	d3 o, d;
+	f3 weight;
+	int depth;
+	uint32_t flags, key;
+};
+
+// TraceContext::raycast, src/main.cpp:63-103.  true = the ray ended (colour in `early`), false = `sf` / `node` hold the hit.
+template <bool COUNT>
+HXR_DEV bool raycast(const HxrSceneDev& S, const RayItem& r, Surface& sf, int& node, f3& early, Tally<COUNT>& tl)
+{
+	tl.add(HC_RAYCASTS);
+	if (r.depth > S.settings.max_trace_depth) { early = mkf(0, 0, 0); return true; }
+	double best = HXR_INF;
+	GeomHit bg;
+	node = -1;
+	for (int ni = 0; ni < S.num_nodes; ni++) {
+		GeomHit g;
+		double w;
+		if (node_query<COUNT>(S, ni, r.o, r.d, g, w, tl) && w < best) {
+			best = w;
+			bg = g;
+			node = ni;
+		}
+	}
+	bool lit = false;
+	f3 lc = mkf(0, 0, 0);
+	for (int li = 0; li < S.num_lights; li++) {
+		const hxr_light& L = S.lights[li];
+		int s = light_query(L, r.o, r.d, best);
+		if (s == -1) { lit = true; lc = mkf(0, 0, 0); }
+		else if (s == 1) { lit = true; lc = (ldf(L.color) * L.power) * L.scale_factor; }
+	}
+	if (lit) { early = (r.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lc; return true; }
+	if (best >= HXR_INF) {
+		early = S.environment.present ? environment_lookup<COUNT>(S, r.d, tl) : ldf(S.settings.background);
+		return true;
+	}
+	surface_of<COUNT>(S, node, r.o, r.d, bg, best, sf, tl);
+	int bump = S.nodes[node].bump;
+	if (bump >= 0) texture_bump<COUNT>(S, bump, sf, tl);
+	return false;
+}
+
+struct RngCtx {
+	uint64_t seed;
+	uint32_t pixel, sample;
+};
+
+// Lambert::computeColor (src/shading.cpp:67-91) / Phong::computeColor (:112-145)
+template <bool COUNT>
+HXR_DEV f3 shade_diffuse(const HxrSceneDev& S, const hxr_shader& sh, const RayItem& r, const Surface& sf, const RngCtx& rc, Tally<COUNT>& tl)
+{
+	f3 base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, r.d, sf, tl) : ldf(sh.color);
+	f3 direct = mkf(0, 0, 0);
+	for (int li = 0; li < S.num_lights; li++) {
+		const hxr_light& L = S.lights[li];
+		int n = light_num_samples(L);
+		f3 sum = mkf(0, 0, 0);
+		for (int i = 0; i < n; i++) {
+			double j1 = 0, j2 = 0;
+			if (L.type == HXR_LIGHT_RECT) hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)li * 4096u + (uint32_t)i), j1, j2);
+			d3 lp;
+			f3 lc;
+			light_sample(L, i, sf.ip, j1, j2, lp, lc);
+			if (is_zero(lc) || !visible<COUNT>(S, lp, sf.ip + sf.norm * 1e-6, tl)) continue;
+			d3 to_ip = sf.ip - lp;   // getLambertTerm, src/shading.cpp:57-65
+			double d2 = len2(to_ip);
+			float lt = (float)fmax(0.0, dot(sf.norm, unit(-to_ip)));
+			if (sh.type == HXR_SHADER_PHONG) {
+				d3 from_light = unit(sf.ip - lp);
+				d3 refl = reflect3(from_light, faceforward(from_light, sf.norm));
+				float cg = (float)dot(-r.d, refl);
+				if (cg > 0) sum = sum + (ldf(sh.specular) * lc) * powf(cg, sh.exponent);
+			}
+			sum = sum + (base * lc) * (float)(lt * L.power / d2);
+		}
+		direct = direct + fdiv(sum, (float)n);
+	}
+	return direct + base * ldf(S.settings.ambient);
+}
+
+HXR_DEV bool refract_dir(d3 i, d3 n, float ior, d3& out)   // refract(), src/shading.cpp:208-214 (float arithmetic)
+{
+	float ndi = (float)dot(i, n);
+	float k = 1 - (ior * ior) * (1 - ndi * ndi);
+	if (k < 0) return false;
+	out = i * (double)ior - n * (double)(ior * ndi + sqrtf(k));
+	return true;
+}
+
+// raytrace(), src/main.cpp:105-113, with the recursion through Reflection / Refraction / Layered
+// (src/shading.cpp:159-232,315-324) flattened into a ray stack and a shader work list.
+template <bool COUNT>
+HXR_DEV f3 trace_whitted(const HxrSceneDev& S, d3 o, d3 d, const RngCtx& rc, Tally<COUNT>& tl)
+{
+	RayItem stack[HXR_RAY_STACK];
+	int top = 0;
+	f3 acc = mkf(0, 0, 0);
+	stack[top++] = RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u};
+	while (top > 0) {
+		RayItem r = stack[--top];
+		Surface sf;
+		int node;
+		f3 early;
+		if (raycast<COUNT>(S, r, sf, node, early, tl)) {
+			acc = acc + early * r.weight;
+			continue;
+		}
+		int sh_stack[HXR_SHADER_STACK];
+		f3 w_stack[HXR_SHADER_STACK];
+		int stop = 0;
+		sh_stack[stop] = S.nodes[node].shader;
+		w_stack[stop++] = r.weight;
+		while (stop > 0) {
+			int si = sh_stack[--stop];
+			f3 w = w_stack[stop];
+			const hxr_shader& sh = S.shaders[si];
+			switch (sh.type) {
+				case HXR_SHADER_LAMBERT:
+				case HXR_SHADER_PHONG: acc = acc + shade_diffuse<COUNT>(S, sh, r, sf, rc, tl) * w; break;
+				case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
+				case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy is rejected at create time)
+					d3 n = faceforward(r.d, sf.norm);
+					if (top < HXR_RAY_STACK)
+						stack[top++] = RayItem{sf.ip + n * 1e-6, reflect3(r.d, n), ldf(sh.color) * w, r.depth + 1, r.flags, hxr_child_key(r.key, si, 0)};
+					break;
+				}
+				case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
+					d3 out;
+					bool ok = dot(r.d, sf.norm) < 0 ? refract_dir(r.d, sf.norm, (float)(1 / sh.ior), out) : refract_dir(r.d, -sf.norm, (float)sh.ior, out);
+					if (ok && top < HXR_RAY_STACK)
+						stack[top++] = RayItem{sf.ip - faceforward(r.d, sf.norm) * 0.000001, out, ldf(sh.color) * w, r.depth + 1, r.flags, hxr_child_key(r.key, si, 0)};
+					break;
+				}
+				case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
+					f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
+					for (int i = sh.num_layers - 1; i >= 0; i--) {
+						const hxr_layer& L = S.layers[sh.first_layer + i];
+						f3 blend = L.texture >= 0 ? texture_sample<COUNT>(S, L.texture, r.d, sf, tl) : ldf(L.blend);
+						if (stop < HXR_SHADER_STACK) {
+							sh_stack[stop] = L.shader;
+							w_stack[stop++] = (w * blend) * rem;
+						}
+						rem = rem * (mkf(1, 1, 1) - blend);
+					}
+					break;
+				}
+				default: break;
+			}
+		}
+	}
+	return acc;
+}
+
+HXR_DEV d3 hemisphere(double u, double v, d3 normal)   // hemisphereSample, src/util.cpp:109-129
+{
+	double theta = 2 * HXR_PI * u;
+	double cphi = 2 * v - 1;
+	double sphi = sqrt(1 - cphi * cphi);
+	d3 dd = mk3(cos(theta) * sphi, cphi, sin(theta) * sphi);
+	if (dot(dd, normal) < 0) dd = -dd;
+	return dd;
+}
+
+// pathtrace(), src/main.cpp:115-169, as a loop: the recursion is a chain (one spawned ray per vertex)
+// and its result is linear in the tail, so each vertex adds its explicit-light term scaled by the
+// throughput and the walk continues with throughput * brdf / pdf.
+template <bool COUNT>
+HXR_DEV f3 trace_path(const HxrSceneDev& S, d3 o, d3 d, const RngCtx& rc, Tally<COUNT>& tl)
+{
+	f3 acc = mkf(0, 0, 0), mult = mkf(1, 1, 1);
+	RayItem r{o, d, mkf(1, 1, 1), 0, 0u, 0u};
+	for (;;) {
+		if (intensity(mult) < 0.001f) break;
+		Surface sf;
+		int node;
+		f3 early;
+		if (raycast<COUNT>(S, r, sf, node, early, tl)) {
+			acc = acc + early * mult;
+			break;
+		}
+		int si = S.nodes[node].shader;
+		const hxr_shader& sh = S.shaders[si];
+		// BRDF::spawnRay: Lambert src/shading.cpp:99-109, Reflection :196-205, Refraction :241-263, default :37-43
+		RayItem nx = r;
+		nx.depth = r.depth + 1;
+		nx.key = hxr_child_key(r.key, si, 0);
+		f3 bc = mkf(1, 0, 0);
+		float pdf = -1;
+		if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG) {
+			d3 N = faceforward(r.d, sf.norm);
+			nx.o = sf.ip + N * 1e-6;
+			double u, v;
+			hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_HEMISPHERE), u, v);
+			nx.d = hemisphere(u, v, N);
+			nx.flags |= HXR_RF_GI_DIFFUSE;
+			f3 base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, r.d, sf, tl) : ldf(sh.color);
+			bc = (base * (float)(1 / HXR_PI)) * (float)dot(nx.d, N);
+			pdf = (float)(1 / (2 * HXR_PI));
+		} else if (sh.type == HXR_SHADER_REFLECTION) {
+			d3 N = faceforward(r.d, sf.norm);
+			nx.o = sf.ip + N * 1e-6;
+			nx.d = reflect3(r.d, N);
+			nx.flags &= ~HXR_RF_GI_DIFFUSE;
+			bc = ldf(sh.color) * 1e+6f;
+			pdf = 1e+6f;
+		} else if (sh.type == HXR_SHADER_REFRACTION) {
+			d3 out;
+			bool ok = dot(r.d, sf.norm) < 0 ? refract_dir(r.d, sf.norm, (float)(1 / sh.ior), out) : refract_dir(r.d, -sf.norm, (float)sh.ior, out);
+			if (ok) {
+				nx.o = sf.ip - faceforward(r.d, sf.norm) * 0.000001;
+				nx.d = out;
+				nx.flags &= ~HXR_RF_GI_DIFFUSE;
+				bc = ldf(sh.color) * 1e+6f;
+				pdf = 1e+6f;
+			}
+		}
+		if (pdf <= 0) break;
+		// explicit light sampling at this vertex (src/main.cpp:133-168)
+		if (S.num_lights > 0) {
+			HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_LIGHT_PICK);
+			const hxr_light& L = S.lights[hxr_below(pick.w0, (uint32_t)S.num_lights)];
+			double solid = light_solid_angle(L, sf.ip);
+			if (solid > 0) {
+				int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples(L));
+				double j1, j2;
+				hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_LIGHT_JITTER), j1, j2);
+				d3 on_light;
+				f3 unused;
+				light_sample(L, idx, sf.ip, j1, j2, on_light, unused);
+				if (visible<COUNT>(S, sf.ip + sf.norm * 1e-6, on_light, tl)) {
+					d3 w_out = unit(on_light - sf.ip);
+					// BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
+					f3 ev = mkf(1, 0, 0);
+					if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG) {
+						f3 base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, r.d, sf, tl) : ldf(sh.color);
+						ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, sf.norm));
+					} else if (sh.type == HXR_SHADER_REFLECTION) {
+						ev = dot(reflect3(r.d, faceforward(r.d, sf.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
+					} else if (sh.type == HXR_SHADER_REFRACTION) {
+						ev = dot(reflect3(r.d, faceforward(r.d, sf.norm)), w_out) > 0.99999999 ? ldf(sh.color) : mkf(0, 0, 0);
+					}
+					f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
+					if (intensity(from_light) > 0) {
+						float p_choose = 1.0f / (float)S.num_lights;
+						float p_hit = (float)(1.0f / solid);
+						acc = acc + fdiv(from_light * mult, p_choose * p_hit);
+					}
+				}
+			}
+		}
+		mult = fdiv(mult * bc, pdf);
+		r = nx;
+	}
+	return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// camera (Camera::getScreenRay src/camera.cpp:65-76, getDOFScreenRay :78-86) and traceSingleRay (src/main.cpp:227-249)
+// ------------------------------------------------------------------------------------------------
+HXR_DEV void camera_ray(const HxrSceneDev& S, int W, int H, double x, double y, double lu, double lv, double stereo, d3& o, d3& d)
+{
+	const hxr_camera& c = S.camera;
+	d3 pos = ld3(c.pos), tl = ld3(c.top_left);
+	o = pos;
+	d3 through = tl + (ld3(c.top_right) - tl) * (x / (double)W) + (ld3(c.bottom_left) - tl) * (y / (double)H);
+	d = unit(through - o);
+	if (stereo != 0) o = o + ld3(c.right) * (stereo * c.stereo_separation);
+	if (c.dof) {
+		double M = c.focal_plane_dist / dot(ld3(c.front), d);
+		d3 T = o + d * M;
+		o = pos + ld3(c.right) * (lu * c.aperture_size) + ld3(c.up) * (lv * c.aperture_size);
+		d = unit_lazy(T - o);
+	}
+}
+
+template <bool COUNT>
+HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, const RngCtx& rc, Tally<COUNT>& tl)
+{
+	double lu = 0, lv = 0;
+	tl.add(HC_SAMPLES);
+	if (S.camera.dof) {   // unitDiskSample, src/util.cpp:101-107
+		for (uint32_t attempt = 0; attempt < 64; attempt++) {
+			hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_LENS + attempt), lu, lv);
+			lu = lu * 2 - 1;
+			lv = lv * 2 - 1;
+			if (!(lu * lu + lv * lv > 1)) break;
+		}
+	}
+	d3 o, d;
+	if (S.camera.stereo_separation == 0.0) {
+		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
+		return S.settings.gi ? trace_path<COUNT>(S, o, d, rc, tl) : trace_whitted<COUNT>(S, o, d, rc, tl);
+	}
+	f3 eye[2];
+	for (int e = 0; e < 2; e++) {
+		camera_ray(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
+		eye[e] = S.settings.gi ? trace_path<COUNT>(S, o, d, rc, tl) : trace_whitted<COUNT>(S, o, d, rc, tl);
+	}
+	float ml = intensity(eye[0]), mr = intensity(eye[1]);
+	return mkf(ml + (eye[0].x - ml) * 0.3f, mr + (eye[1].y - mr) * 0.3f, mr + (eye[1].z - mr) * 0.3f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// work mapping
+// ------------------------------------------------------------------------------------------------
+// Pixels of a shard are numbered tile by tile; inside a tile in 8x8 blocks (row-major), inside a block
+// along a Morton curve, so every aligned group of 4 / 16 / 64 consecutive pixels is a 2x2 / 4x4 / 8x8
+// square of the image: the lanes of a wave stay spatially coherent for every power-of-two spp.
+HXR_DEV void morton6(uint32_t m, int& x, int& y)
+{
+	x = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
+	y = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
+}
+
+HXR_DEV bool shard_pixel(const HxrLaunch& P, uint32_t q, int& x, int& y)
+{
+	uint32_t per_tile = (uint32_t)(P.tile_size * P.tile_size);
+	uint32_t lt = q / per_tile, in = q - lt * per_tile;
+	if (lt >= (uint32_t)P.num_shard_tiles) return false;
+	uint32_t t = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;   // row-major tile number
+	int tx = (int)(t % (uint32_t)P.tiles_x), ty = (int)(t / (uint32_t)P.tiles_x);
+	int bpr = P.tile_size / 8;
+	uint32_t blk = in >> 6;
+	int mx, my;
+	morton6(in & 63u, mx, my);
+	x = tx * P.tile_size + (int)(blk % (uint32_t)bpr) * 8 + mx;
+	y = ty * P.tile_size + (int)(blk / (uint32_t)bpr) * 8 + my;
+	return x < P.W && y < P.H;
+}
+
+HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
+{
+	if (P.out_tiles) {
+		uint32_t per_tile = (uint32_t)(P.tile_size * P.tile_size);
+		uint32_t lt = q / per_tile;
+		int lx = x % P.tile_size, ly = y % P.tile_size;
+		return P.out + ((size_t)lt * per_tile + (size_t)ly * P.tile_size + lx) * 3;
+	}
+	return (float*)((char*)P.out + (size_t)y * P.out_stride) + (size_t)x * 3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the render kernel: persistent wavefronts, one ray packet (64 camera samples) per dispenser ticket
+// ------------------------------------------------------------------------------------------------
+#define HXR_BLOCK 256
+
+template <bool COUNT>
+__global__ __launch_bounds__(HXR_BLOCK) void hxr_render_kernel(const HxrSceneDev* __restrict__ Sp, HxrLaunch P)
+{
+	const HxrSceneDev& S = *Sp;
+	__shared__ float lds_rgb[HXR_BLOCK / 64][64][3];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	Tally<COUNT> tl;
+	tl.clear();
+	const int spp = P.spp;
+	const int lanes_per_pixel = spp < 64 ? spp : 64;          // samples of one pixel resident in the wave
+	const int ppc = P.pixels_per_chunk;                         // 64 / spp for spp <= 64, else 1
+	const int rounds = (spp + 63) / 64;
+	// pass 3 sizes itself from the device-side count of flagged pixels (no host round trip between the passes)
+	const uint32_t num_chunks = P.mode == 2 ? ((uint32_t)*P.aa_count + (uint32_t)ppc - 1u) / (uint32_t)ppc : P.num_chunks;
+	for (;;) {
+		uint32_t chunk = 0;
+		if (lane == 0) chunk = atomicAdd(P.work_counter, 1u);
+		chunk = __builtin_amdgcn_readfirstlane(chunk);
+		if (chunk >= num_chunks) break;
+		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
+		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
+		bool live = slot < ppc;
+		// which pixel
+		int x = 0, y = 0;
+		uint32_t q = 0;
+		if (P.mode == 2) {        // AA taps: aa_list holds frame pixel numbers, 4 taps each
+			uint32_t e = chunk * (uint32_t)ppc + (uint32_t)slot;
+			live = live && e < (uint32_t)*P.aa_count;
+			if (live) { int pix = P.aa_list[e]; x = pix % P.W; y = pix / P.W; }
+		} else {
+			q = chunk * (uint32_t)ppc + (uint32_t)slot;
+			uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+			if (q < tile_pixels) live = live && shard_pixel(P, q, x, y);
+			else {                // halo pixels of a sharded adaptive-AA frame
+				uint32_t e = q - tile_pixels;
+				live = live && e < (uint32_t)P.num_extra_pixels;
+				if (live) { int pix = P.extra_pixels[e]; x = pix % P.W; y = pix / P.W; }
+			}
+		}
+		f3 sum = mkf(0, 0, 0);
+		if (live) {
+			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
+			for (int rd = 0; rd < rounds; rd++) {
+				int s = sub + rd * 64;
+				if (s >= spp) break;
+				double sx = x, sy = y;
+				if (P.mode == 1) {          // renderWithMonteCarlo: x + randDouble(), y + randDouble() (src/main.cpp:373-375)
+					rc.sample = (uint32_t)s;
+					double jx, jy;
+					hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_PIXEL_JITTER), jx, jy);
+					sx = x + jx;
+					sy = y + jy;
+				} else if (P.mode == 2) {   // pass 3 taps 1..4 of AA_KERNEL; `x + 0.6f` is float arithmetic (src/main.cpp:255-261,336)
+					const float kx[4] = {0.6f, 0.3f, 0.0f, 0.6f}, ky[4] = {0.0f, 0.3f, 0.6f, 0.6f};
+					rc.sample = (uint32_t)(s + 1);
+					sx = (double)((float)x + kx[s]);
+					sy = (double)((float)y + ky[s]);
+				}
+				f3 c = trace_sample<COUNT>(S, P.W, P.H, sx, sy, rc, tl);
+				sum = (rd == 0) ? c : sum + c;
+			}
+		}
+		// combine the samples of each pixel in sample order (the reference adds them one by one, src/main.cpp:372-377)
+		lds_rgb[wave][lane][0] = sum.x;
+		lds_rgb[wave][lane][1] = sum.y;
+		lds_rgb[wave][lane][2] = sum.z;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (live && sub == 0) {
+			const bool in_tile = P.mode != 2 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+			float* dst = in_tile ? out_pixel(P, q, x, y) : (float*)((char*)P.out + (size_t)y * P.out_stride) + (size_t)x * 3;
+			f3 t = (P.mode == 2) ? mkf(dst[0], dst[1], dst[2]) : mkf(0, 0, 0);   // pass 3 adds onto the pass-1 colour
+			for (int i = 0; i < lanes_per_pixel; i++) {
+				const float* s = lds_rgb[wave][lane + i];
+				t = mkf(t.x + s[0], t.y + s[1], t.z + s[2]);
+			}
+			if (P.mode == 1) t = t * (1.0f / spp);
+			else if (P.mode == 2) t = t * (1.0f / 5);
+			dst[0] = t.x;
+			dst[1] = t.y;
+			dst[2] = t.z;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (COUNT && P.counters) {
+		for (int i = 0; i < HC_NUM; i++) {
+			uint32_t v = tl.c[i];
+			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+			if (lane == 0 && v) atomicAdd(&P.counters[i], (unsigned long long)v);
+		}
+	}
+}
+
+// detectAApixels, src/main.cpp:192-222: a pixel needs AA when any channel differs from any of its 8
+// neighbours by more than 0.075 after clamping to 1.  Flagged pixels are appended to a compact list with
+// one atomic per wave (ballot + prefix count).
+__global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, const float* __restrict__ frame, size_t stride, int32_t* list,
+                                                                   int32_t* count)
+{
+	uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < ((tile_pixels + 63u) & ~63u); q += gridDim.x * blockDim.x) {
+		int x, y;
+		bool need = false;
+		if (q < tile_pixels && shard_pixel(P, q, x, y)) {
+			const float* me = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
+			for (int dy = -1; dy <= 1 && !need; dy++)
+				for (int dx = -1; dx <= 1 && !need; dx++) {
+					if (!dx && !dy) continue;
+					int nx = x + dx, ny = y + dy;
+					if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+					const float* nb = (const float*)((const char*)frame + (size_t)ny * stride) + (size_t)nx * 3;
+					for (int c = 0; c < 3; c++)
+						if (fabsf(fminf(1.0f, me[c]) - fminf(1.0f, nb[c])) > 0.075f) { need = true; break; }
+				}
+		}
+		unsigned long long mask = __ballot(need);
+		int lane = threadIdx.x & 63;
+		int base = 0;
+		if (lane == 0 && mask) base = atomicAdd(count, __popcll(mask));
+		base = __shfl(base, 0, 64);
+		if (need) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = y * P.W + x;
+	}
+}
+
+// own tiles of a row-major frame -> tile-major shard buffer (sharded adaptive-AA frames render into a scratch frame)
+__global__ void hxr_extract_tiles_kernel(HxrLaunch P, const float* __restrict__ frame, size_t stride, float* tiles)
+{
+	uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < tile_pixels; q += gridDim.x * blockDim.x) {
+		int x, y;
+		if (!shard_pixel(P, q, x, y)) continue;
+		const float* src = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
+		HxrLaunch T = P;
+		T.out = tiles;
+		T.out_tiles = 1;
+		float* dst = out_pixel(T, q, x, y);
+		dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+	}
+}
+
+// tile-major shard buffers (rank-major, as gathered) -> row-major frame
+__global__ void hxr_assemble_kernel(const float* __restrict__ gathered, size_t per_rank_floats, float* frame, size_t stride, int W, int H,
+                                    int tile_size, int tiles_x, int tiles_y, int shard_count)
+{
+	size_t total = (size_t)tiles_x * tiles_y * tile_size * tile_size;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		int per_tile = tile_size * tile_size;
+		int t = (int)(i / per_tile), in = (int)(i % per_tile);
+		int x = (t % tiles_x) * tile_size + in % tile_size, y = (t / tiles_x) * tile_size + in / tile_size;
+		if (x >= W || y >= H) continue;
+		int rank = t % shard_count, lt = t / shard_count;
+		const float* src = gathered + (size_t)rank * per_rank_floats + ((size_t)lt * per_tile + in) * 3;
+		float* dst = (float*)((char*)frame + (size_t)y * stride) + (size_t)x * 3;
+		dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+	}
+}
+
+// Color::toRGB32 through the 4097-entry table (src/color.h:84-90, src/sdl.cpp:404-419)
+__global__ void hxr_quantize_kernel(const float* __restrict__ frame, size_t stride, int W, int H, const uint8_t* __restrict__ lut, uint8_t* bgr)
+{
+	size_t total = (size_t)W * H;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		int x = (int)(i % W), y = (int)(i / W);
+		const float* p = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			float v = p[2 - c];
+			uint8_t o = v <= 0 ? 0 : (v >= 1 ? 255 : lut[(int)(v * 4096.0f)]);
+			bgr[i * 3 + c] = o;
+		}
+	}
+}
