@@ -1,0 +1,223 @@
+"""Benchmark of the hot path: frames of BASELINE.json's headline workload through the C-ABI HIP module.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of `data/meshes.hexray` at 1920x1080 with 16 samples per pixel (Camera `dof on,
+numSamples 16` -- SURVEY.md section 8d, config 3b), i.e. one pass of the per-pixel / per-sample raytrace
+loop over 33,177,600 camera samples.  The scene is resident in HBM before the timed region starts and the
+frame stays in HBM (the PCIe-inclusive rate is noted in DESIGN.md).  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the frame's 32x32 tiles are dealt round-robin to the ranks, each
+rank renders its tiles, and ONE RCCL gather brings them to rank 0, which assembles the frame: the total
+work per step is fixed, so scaling is "strong".
+
+Rank 0 prints one JSON line.  `roofline.achieved` is algorithmic bytes per launch (SURVEY.md section 8d
+formula over the frame's own work counters) divided by the render kernel's mean duration measured with HIP
+events on the launch stream; `cpu_baseline` times the CPU oracle (test infrastructure, a port of the
+reference's algorithm) on this host's cores for the same frame, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, overlay kwargs, description)
+    "meshes16": ("meshes.hexray", dict(width=1920, height=1080, dof=True, num_samples=16),
+                 "data/meshes.hexray 1920x1080 x 16 spp (Camera dof on, numSamples 16; renderWithMonteCarlo)"),
+    "meshes_aa": ("meshes.hexray", dict(width=1920, height=1080),
+                  "data/meshes.hexray 1920x1080 adaptive 5-tap AA (as shipped; renderWithoutMonteCarlo)"),
+    "simple1": ("simple.hexray", dict(width=1920, height=1080, want_aa=False),
+                "data/simple.hexray 1920x1080 x 1 spp (EXR cubemap not decoded: black environment)"),
+    "heightfield16": ("heightfield.hexray", dict(width=1920, height=1080, dof=True, num_samples=16),
+                      "data/heightfield.hexray 1920x1080 x 16 spp (EXR cubemap not decoded: black environment)"),
+    "smallpt256": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=256), "data/smallpt.hexray 1920x1080 x 256 paths"),
+    "smallpt16": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=16), "data/smallpt.hexray 1920x1080 x 16 paths"),
+}
+TILE = 32
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(c, width, height):
+    """bytes the algorithm must read / write for one frame, from its work counters."""
+    return (24 * c["kd_visits"] + 4 * c["leaf_indices"] + 100 * c["tri_tests"] + 192 * c["mesh_hits"] + 48 * c["tex_bilinear"]
+            + 48 * c["env_bilinear"] + 4 * (c["hf_highest"] + c["hf_height"]) + 96 * c["hf_normals"] + 12 * width * height)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="meshes16", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import hexray_amd as hx
+    from hexray_amd.distributed import gather_tiles, padded_tiles_per_rank
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    scene_name, ov, description = WORKLOADS[args.workload]
+    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+    hx.init(local_rank)
+    torch.cuda.set_device(local_rank)
+    ds = hx.DeviceScene(hs)
+    W, H = hs.settings.frame_width, hs.settings.frame_height
+    stream = torch.cuda.current_stream().cuda_stream
+
+    probe = hx.frame_params()
+    # resolve the samples per pixel the way render() does (reference src/main.cpp:421-424)
+    spp = max(hs.camera.num_samples if hs.camera.dof else 0, hs.settings.num_paths if hs.settings.gi else 0)
+    samples_per_frame = W * H * (spp if spp > 0 else 1)
+
+    if world == 1:
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        params = hx.frame_params(tile_size=TILE)
+
+        def step():
+            ds.render_device(params, frame.data_ptr(), W * 12, stream)
+    else:
+        slots = padded_tiles_per_rank(W, H, TILE, world)
+        local = torch.zeros(slots * TILE * TILE * 3, dtype=torch.float32, device="cuda")
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+        params = hx.frame_params(tile_size=TILE, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
+
+        def step():
+            ds.render_device(params, local.data_ptr(), 0, stream)
+            gathered = gather_tiles(local, world, rank)
+            if rank == 0:
+                ds.assemble_frame(params, gathered.data_ptr(), slots * TILE * TILE * 12, frame.data_ptr(), W * 12, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            pass
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # render-kernel duration (HIP events on the launch stream): measured over separate, individually
+    # synchronised launches of the same frame so that every event pair is read back
+    for _ in range(min(args.steps, 10)):
+        step()
+        torch.cuda.synchronize()
+        kernel_ms.append(ds.last_kernel_ms())
+    kernel_ms_mean = float(np.mean(kernel_ms))
+
+    # work counters of one frame (instrumented kernel build, outside the timed region)
+    cparams = hx.frame_params(tile_size=TILE, collect_counters=True)
+    if world == 1:
+        ds.render_device(cparams, frame.data_ptr(), W * 12, stream)
+        torch.cuda.synchronize()
+        counters = ds.counters()
+    else:
+        counters = None
+
+    result = None
+    if rank == 0:
+        value = samples_per_frame * args.steps / elapsed / 1e6
+        result = {
+            "metric": "Msamples/s (primary+secondary rays) at 1920x1080",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "scene asset data/%s shipped with the reference (no external dataset)" % scene_name,
+            "config": {"workload": description, "width": W, "height": H, "spp": spp if spp > 0 else 1, "tile_size": TILE,
+                       "parallelism": "tile-shard x%d, one RCCL gather" % world if world > 1 else "single GPU", "rng_seed": int(probe.rng_seed)},
+        }
+        if counters is not None:
+            abytes = algorithmic_bytes(counters, W, H)
+            achieved = abytes / (kernel_ms_mean * 1e-3) / 1e9
+            rays = counters["raycasts"] + counters["shadow_queries"]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            result["roofline"] = {
+                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "bytes_per_sample": round(abytes / samples_per_frame, 2),
+                "kernel": "hxr_render_kernel<false>", "kernel_ms": round(kernel_ms_mean, 4),
+            }
+            result["rays_per_sample"] = round(rays / counters["camera_samples"], 3)
+            result["Mrays_per_s"] = round(rays / (kernel_ms_mean * 1e-3) / 1e6, 1)
+        else:
+            result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                  "kernel_ms": round(kernel_ms_mean, 4), "note": "per-rank kernel time of rank 0; counters are collected at N=1 only"}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene_name, ov, samples_per_frame)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(scene_name, ov, samples_per_frame):
+    """The CPU oracle (a port of the reference's algorithm; oracle/hxo_oracle.c) on this host's cores: the
+    workload frame (at reduced resolution when the full frame would take minutes), one warm-up plus repeats
+    until about 10 s of CPU wall time have been spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hexray_amd as hx
+    from oracle_binding import oracle_lib, oracle_render
+    threads = min(os.cpu_count() or 1, oracle_lib().hxo_max_threads())
+    ov = dict(ov)
+    what = "the whole workload frame"
+    if samples_per_frame > 40_000_000:   # e.g. 256 paths per pixel: minutes on a CPU
+        ov["width"], ov["height"] = ov["width"] // 4, ov["height"] // 4
+        samples_per_frame //= 16
+        what = "the workload at %dx%d (1/16 of the pixels, same spp)" % (ov["width"], ov["height"])
+    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+    oracle_render(hs, hx.frame_params(), threads=threads)   # warm-up (thread pool, page faults)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all < 12.0 or len(times) < 2):
+        t = time.perf_counter()
+        oracle_render(hs, hx.frame_params(), threads=threads)
+        times.append(time.perf_counter() - t)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(samples_per_frame / med / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "%s, %d runs after one warm-up, median %.3f s (min %.3f, max %.3f); gcc -O3 -ffast-math -march=haswell, OpenMP"
+                      % (what, len(times), med, min(times), max(times))}
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,7 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 		-o hexray_amd/lib/libhexray_hip.so hexray_amd/csrc/hxr_api.hip
 fi
 if [ "$what" = all ] || [ "$what" = cli ]; then
-	g++ $CXXFLAGS -o hexray_amd/bin/hexray hexray_amd/host/main.cpp -Lhexray_amd/lib -lhexray_host -ldl \
+	g++ $CXXFLAGS -o hexray_amd/bin/hexray hexray_amd/host/main.cpp -Lhexray_amd/lib -lhexray_host -lhexray_hip \
 		-Wl,-rpath,'$ORIGIN/../lib'
 fi
 if [ "$what" = all ] || [ "$what" = ref ]; then

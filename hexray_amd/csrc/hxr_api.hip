@@ -223,18 +223,22 @@ struct Plan {   // resolved frame parameters
 
 int resolve(const hxr_scene* s, const hxr_frame_params* fp, Plan& p)
 {
-	if (!s || !fp) { set_err("null scene / params"); return HXR_E_INVALID; }
+	if (!fp) { set_err("null params"); return HXR_E_INVALID; }
+	if (!s && (fp->width <= 0 || fp->height <= 0 || fp->mode == HXR_MODE_AUTO)) {   // tile bookkeeping may be asked without a scene
+		set_err("without a scene the frame size and mode must be explicit");
+		return HXR_E_INVALID;
+	}
 	p.W = fp->width > 0 ? fp->width : s->settings.frame_width;
 	p.H = fp->height > 0 ? fp->height : s->settings.frame_height;
 	if (p.W <= 0 || p.H <= 0 || p.W > 1920 || p.H > 1920) { set_err("frame %dx%d outside 1..1920 (VFB_MAX_SIZE)", p.W, p.H); return HXR_E_INVALID; }
 	p.mode = fp->mode;
 	p.spp = fp->spp;
 	int rpp = 0;   // render(): raysPerPixel = max(dof ? numSamples : 0, gi ? numPaths : 0)  (src/main.cpp:421-424)
-	if (s->camera.dof) rpp = s->camera.num_samples;
-	if (s->settings.gi) rpp = std::max(rpp, s->settings.num_paths);
+	if (s && s->camera.dof) rpp = s->camera.num_samples;
+	if (s && s->settings.gi) rpp = std::max(rpp, s->settings.num_paths);
 	if (p.mode == HXR_MODE_AUTO) {
 		if (rpp > 0) { p.mode = HXR_MODE_MONTE_CARLO; if (p.spp <= 0) p.spp = rpp; }
-		else p.mode = s->settings.want_aa ? HXR_MODE_ADAPTIVE_AA : HXR_MODE_SINGLE;
+		else p.mode = (s && s->settings.want_aa) ? HXR_MODE_ADAPTIVE_AA : HXR_MODE_SINGLE;
 	}
 	if (p.mode == HXR_MODE_MONTE_CARLO) { if (p.spp <= 0) p.spp = rpp > 0 ? rpp : 1; }
 	else if (p.mode == HXR_MODE_SINGLE || p.mode == HXR_MODE_ADAPTIVE_AA) p.spp = 1;

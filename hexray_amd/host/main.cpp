@@ -1,0 +1,102 @@
+// hexray -- headless command-line front end of the MI355X render path.
+// Stands where the reference's main() / renderThreadEntry() / renderStatic() stand (reference
+// src/main.cpp:506-569): parse the scene, prepare it, render one frame, report "Elapsed time", save
+// the frame.  The reference opens an SDL window and can only save on F12 (src/sdl.cpp:103-116,201);
+// there is no window here, and W x H / spp / AA can be overridden from the command line (the
+// reference reads them from the scene file only).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "hexray_hip.h"
+#include "host_api.h"
+
+static void usage()
+{
+	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
+	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc] [--seed S] [--device D]\n"
+	       "              [--frames N] [--out frame.bmp|frame.raw] [--counters]\n");
+}
+
+int main(int argc, char** argv)
+{
+	std::string scene = "data/simple.hexray", out;
+	std::string g, c;   // overlay lines for GlobalSettings / Camera
+	hxr_frame_params fp;
+	memset(&fp, 0, sizeof fp);
+	fp.rng_seed = 5489;
+	int device = 0, frames = 1;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+		if (a == "--width") g += std::string("frameWidth ") + next() + "\n";
+		else if (a == "--height") g += std::string("frameHeight ") + next() + "\n";
+		else if (a == "--aa") g += std::string("wantAA ") + next() + "\n";
+		else if (a == "--gi") g += std::string("gi ") + next() + "\n";
+		else if (a == "--paths") g += std::string("numPaths ") + next() + "\n";
+		else if (a == "--dof") c += std::string("dof ") + next() + "\n";
+		else if (a == "--spp") { const char* v = next(); c += std::string("numSamples ") + v + "\n"; fp.spp = atoi(v); }
+		else if (a == "--mode") {
+			std::string m = next();
+			fp.mode = m == "single" ? HXR_MODE_SINGLE : m == "aa" ? HXR_MODE_ADAPTIVE_AA : m == "mc" ? HXR_MODE_MONTE_CARLO : HXR_MODE_AUTO;
+		} else if (a == "--seed") fp.rng_seed = strtoull(next(), nullptr, 10);
+		else if (a == "--device") device = atoi(next());
+		else if (a == "--frames") frames = atoi(next());
+		else if (a == "--out") out = next();
+		else if (a == "--counters") fp.collect_counters = 1;
+		else if (a == "-h" || a == "--help") { usage(); return 0; }
+		else if (!a.empty() && a[0] != '-') scene = a;
+		else { usage(); return 2; }
+	}
+	std::string overlay = "GlobalSettings {\nprepassSamples 0\ninteractive off\n" + g + "}\n";
+	if (!c.empty()) overlay += "Camera {\n" + c + "}\n";
+	if (fp.mode != HXR_MODE_MONTE_CARLO) fp.spp = 0;
+
+	char err[1024] = "";
+	hxh_scene* hs = hxh_scene_load(scene.c_str(), overlay.c_str(), err, sizeof err);
+	if (!hs) {
+		printf("Could not parse the scene file (%s)!\n%s\n", scene.c_str(), err);
+		return 1;
+	}
+	for (int i = 0; i < hxh_scene_num_warnings(hs); i++) fprintf(stderr, "%s\n", hxh_scene_warning(hs, i));
+	const hxr_scene_desc* d = hxh_scene_desc(hs);
+	for (int m = 0;; m++) {
+		int nodes, leaves, depth;
+		double avg_depth, avg_tris;
+		if (hxh_scene_kd_stats(hs, m, &nodes, &leaves, &depth, &avg_depth, &avg_tris)) break;
+		if (!nodes) continue;
+		// the lines Mesh::beginRender prints (src/mesh.cpp:39-47)
+		printf("K-d Tree statistics:\n   nodes            : %d\n   leaf nodes       : %d\n   max depth        : %d\n"
+		       "   avg depth        : %.1f\n   avg tris per leaf: %.1f\n", nodes, leaves, depth, avg_depth, avg_tris);
+	}
+	if (hxr_init(device)) { printf("GPU init failed: %s\n", hxr_last_error()); return 1; }
+	auto t0 = std::chrono::steady_clock::now();
+	hxr_scene* ds = hxr_scene_create(d);
+	if (!ds) { printf("hxr_scene_create failed: %s\n", hxr_last_error()); return 1; }
+	int W = d->settings.frame_width, H = d->settings.frame_height;
+	std::vector<float> vfb((size_t)W * H * 3);
+	int rc = 0;
+	for (int f = 0; f < frames && rc == 0; f++) rc = hxr_render(ds, &fp, vfb.data(), (size_t)W * 12, nullptr, nullptr, nullptr);
+	auto t1 = std::chrono::steady_clock::now();
+	if (rc < 0) { printf("hxr_render failed: %s\n", hxr_last_error()); return 1; }
+	printf("Elapsed time: %.2f seconds.\n", std::chrono::duration<double>(t1 - t0).count());
+	printf("render kernel: %.3f ms (%d x %d)\n", hxr_last_kernel_ms(ds), W, H);
+	if (fp.collect_counters) {
+		hxr_counters k;
+		if (!hxr_get_counters(ds, &k))
+			printf("samples %llu raycasts %llu shadow %llu node tests %llu box tests %llu triangle tests %llu\n", (unsigned long long)k.camera_samples,
+			       (unsigned long long)k.raycasts, (unsigned long long)k.shadow_queries, (unsigned long long)k.node_tests, (unsigned long long)k.bbox_tests,
+			       (unsigned long long)k.tri_tests);
+	}
+	if (!out.empty()) {
+		bool raw = out.size() > 4 && out.substr(out.size() - 4) == ".raw";
+		int w = raw ? hxh_save_raw(out.c_str(), vfb.data(), W, H, (size_t)W * 12) : hxh_save_bmp(out.c_str(), vfb.data(), W, H, (size_t)W * 12);
+		if (w) { printf("cannot write %s\n", out.c_str()); return 1; }
+	}
+	hxr_scene_destroy(ds);
+	hxh_scene_free(hs);
+	printf("Exited cleanly\n");
+	return 0;
+}

@@ -326,7 +326,8 @@ int hxr_render_device(hxr_scene* scene, const hxr_frame_params* params, float* d
 /* Bytes hxr_render_device writes for these parameters (layout FRAME: height*row_stride_bytes). */
 size_t hxr_output_bytes(const hxr_scene* scene, const hxr_frame_params* params, size_t row_stride_bytes);
 
-/* Number of tiles this shard owns, and the pixel rectangle of its i-th tile. */
+/* Number of tiles this shard owns, and the pixel rectangle of its i-th tile.  Pure bookkeeping: `scene`
+ * may be NULL when width, height and mode are given explicitly (no GPU is touched). */
 int hxr_shard_tile_count(const hxr_scene* scene, const hxr_frame_params* params);
 int hxr_shard_tile_rect(const hxr_scene* scene, const hxr_frame_params* params, int i,
                         int* x0, int* y0, int* x1, int* y1);

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Regenerates tests/golden/reference_vectors.json from the reference's own code (needs /root/reference).
+set -e
+cd "$(dirname "$0")/../.."
+make -s -C oracle ref
+oracle/_ref/ref_harness > tests/golden/reference_vectors.json
+python3 -c "import json; d=json.load(open('tests/golden/reference_vectors.json')); print({k:(len(v) if isinstance(v,list) else v) for k,v in d.items()})"

@@ -1,0 +1,193 @@
+"""Host side (loader / flattener / output) on the CPU: parser behaviour, asset decoding, kd-tree builder
+statistics recorded from the reference, bucket order, BMP output."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import hexray_amd as hx
+from conftest import scene_path
+from desc_types import desc_of
+
+# "nodes / leaf nodes / max depth / avg depth / avg tris per leaf" printed by the reference's
+# Mesh::beginRender (reference src/mesh.cpp:39-47) for the config scenes, as recorded from the
+# reference binary in SURVEY.md section 8c(iv).
+REFERENCE_KD_STATS = {
+    "simple.hexray": [(15, 8, 3, None, None), (6003, 3002, 65, 18.0, 11.2), (3431, 1716, 22, 12.6, 11.5)],
+    "meshes.hexray": [(15, 8, 3, None, None), (1467, 734, 65, 27.6, 7.7), (6007, 3004, 65, 18.0, 11.2)],
+}
+
+
+@pytest.mark.parametrize("scene", sorted(REFERENCE_KD_STATS))
+def test_kd_builder_matches_reference_statistics(scene):
+    hs = hx.HostScene(scene_path(scene))
+    got = hs.kd_stats()
+    want = REFERENCE_KD_STATS[scene]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[:3] == w[:3]
+        if w[3] is not None:
+            assert round(g[3], 1) == w[3] and round(g[4], 1) == w[4]
+
+
+def test_kd_tree_structure_is_consistent():
+    hs = hx.HostScene(scene_path("meshes.hexray"))
+    d = desc_of(hs)
+    for mi in range(d.num_meshes):
+        m = d.meshes[mi]
+        seen_leaf_entries = 0
+        for ni in range(m.num_kd_nodes):
+            n = d.kd_nodes[m.first_kd_node + ni]
+            if n.axis == 3:
+                assert 0 <= n.first and n.first + n.count <= m.num_leaf_indices
+                seen_leaf_entries += n.count
+                for k in range(n.count):
+                    assert 0 <= d.leaf_indices[m.first_leaf_index + n.first + k] < m.num_triangles
+            else:
+                assert 0 <= n.axis <= 2 and n.first + 1 < m.num_kd_nodes
+                for c in (n.first, n.first + 1):
+                    assert d.kd_nodes[m.first_kd_node + c].parent == ni
+                assert m.bbox_min[n.axis] <= n.split <= m.bbox_max[n.axis]
+        assert seen_leaf_entries == m.num_leaf_indices
+        assert d.kd_nodes[m.first_kd_node].parent == -1
+
+
+def test_all_shipped_scenes_load():
+    """The reference's only test is `for fn in data/*.hexray; do hexray $fn` (scripts/test_all_scenes.sh:5)."""
+    import glob
+    names = sorted(glob.glob(os.path.join(scene_path(""), "*.hexray")) + glob.glob(os.path.join(scene_path("hw10"), "*.hexray"))
+                   + glob.glob(os.path.join(scene_path("hw12"), "*.hexray")))
+    assert len(names) >= 13
+    for n in names:
+        hs = hx.HostScene(n)
+        assert desc_of(hs).num_nodes >= 1, n
+
+
+def test_settings_camera_defaults_and_overlay():
+    hs = hx.HostScene(scene_path("meshes.hexray"))
+    s, c = hs.settings, hs.camera
+    assert (s.frame_width, s.frame_height, s.max_trace_depth, s.want_aa, s.gi) == (640, 480, 7, 1, 0)
+    assert c.dof == 0 and c.num_samples == 20   # "numSamples 20 // change to 50 ..." -- trailing comment stripped
+    assert abs(c.aperture_size - 2.5 / 5.6) < 1e-15 and c.focal_plane_dist == 21.48
+    hs2 = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(1920, 1080, want_aa=False, dof=True, num_samples=16))
+    s, c = hs2.settings, hs2.camera
+    assert (s.frame_width, s.frame_height, s.want_aa, c.dof, c.num_samples) == (1920, 1080, 0, 1, 16)
+
+
+def test_camera_basis_is_orthonormal_and_matches_fov():
+    hs = hx.HostScene(scene_path("simple.hexray"))
+    c = hs.camera
+    up, right, front = np.array(c.up), np.array(c.right), np.array(c.front)
+    for v in (up, right, front):
+        assert abs(np.linalg.norm(v) - 1) < 1e-12
+    assert abs(up @ right) < 1e-12 and np.allclose(np.cross(right, up), front, atol=1e-12)
+    # the field of view is matched on the frame DIAGONAL (reference src/camera.cpp:39-41)
+    pos, tl, tr, bl = (np.array(x) for x in (c.pos, c.top_left, c.top_right, c.bottom_left))
+    centre = (tr + bl) / 2
+    half_diag = np.linalg.norm(tl - centre) / np.linalg.norm(centre - pos)
+    assert abs(np.degrees(np.arctan(half_diag)) * 2 - 100) < 1e-9
+
+
+def test_parser_errors_are_reported():
+    with pytest.raises(ValueError, match="Unknown object class"):
+        hx.HostScene(scene_path("simple.hexray"), "Torus t {\n}\n")
+    with pytest.raises(ValueError, match="outside the allowed bounds"):
+        hx.HostScene(scene_path("simple.hexray"), "Camera {\n fov 500\n}\n")
+    with pytest.raises(ValueError, match="not defined"):
+        hx.HostScene(scene_path("simple.hexray"), "Node extra {\n geometry nothing\n shader flat\n}\n")
+    with pytest.raises(ValueError):
+        hx.HostScene(scene_path("does_not_exist.hexray"))
+
+
+def test_parser_comment_and_quote_rules(tmp_path):
+    text = """GlobalSettings {
+	frameWidth 32   // trailing comment
+	frameHeight 24  # hash comment
+}
+/* block comment
+Camera bogus { }
+*/
+Camera cam {
+	pos (1, 2, 3)
+}
+Plane floor {
+}
+Lambert l {
+}
+Node n {
+	geometry floor
+	shader l
+	translate (1, 0, 0)
+	scale (2, 2, 2)
+}
+"""
+    p = tmp_path / "t.hexray"
+    p.write_text(text)
+    hs = hx.HostScene(str(p))
+    assert (hs.settings.frame_width, hs.settings.frame_height) == (32, 24)
+    assert list(hs.camera.pos) == [1.0, 2.0, 3.0]
+    T = desc_of(hs).nodes[0].T
+    assert list(T.offset) == [1.0, 0.0, 0.0] and T.m[0] == 2.0 and T.inv_m[0] == 0.5
+
+
+def test_bmp_decoder_against_pillow():
+    from PIL import Image
+    for rel in ("texture/zar-texture.bmp", "texture/heightfield.bmp", "env/mountain/posx.bmp"):
+        ours = hx.load_image(scene_path(rel))
+        ref = np.asarray(Image.open(scene_path(rel)).convert("RGB"), dtype=np.float32) / np.float32(255.0)
+        assert ours.shape == ref.shape
+        # the host library is built with the reference's Release flags (-ffast-math turns `/ 255.0f` into a
+        # reciprocal multiply), so texel values may differ from the exact quotient by one ulp
+        assert np.array_equal(np.round(ours * 255).astype(np.uint8), np.round(ref * 255).astype(np.uint8))
+        assert np.allclose(ours, ref, rtol=2.5e-7, atol=0)
+
+
+def test_bucket_list_is_the_reference_zigzag():
+    b = hx.bucket_list(1920, 1080, 64)
+    assert len(b) == 30 * 17   # 510 buckets at 1080p
+    assert tuple(b[0]) == (0, 0, 64, 64) and tuple(b[29]) == (1856, 0, 1920, 64)
+    assert tuple(b[30]) == (1856, 64, 1920, 128)          # odd rows run right to left
+    assert tuple(b[-1])[3] == 1080 and all(r[2] <= 1920 and r[3] <= 1080 for r in b)
+    covered = np.zeros((1080, 1920), dtype=np.int32)
+    for x0, y0, x1, y1 in b:
+        covered[y0:y1, x0:x1] += 1
+    assert covered.min() == 1 and covered.max() == 1
+
+
+def test_bmp_writer_layout(tmp_path):
+    frame = np.zeros((3, 5, 3), dtype=np.float32)
+    frame[0, 0] = (1.0, 0.0, 0.0)
+    frame[2, 4] = (0.0, 0.5, 2.0)
+    path = str(tmp_path / "o.bmp")
+    hx.save_bmp(path, frame)
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"BM" and struct.unpack_from("<iii", raw, 2)[2] == 54
+    w, h = struct.unpack_from("<ii", raw, 18)
+    assert (w, h) == (5, 3) and len(raw) == 54 + 16 * 3   # rows padded to 4 bytes
+    from PIL import Image
+    px = np.asarray(Image.open(path).convert("RGB"))
+    assert tuple(px[0, 0]) == (255, 0, 0)
+    lib = hx.host_lib()
+    import ctypes
+    assert tuple(px[2, 4]) == (0, lib.hxh_srgb8(ctypes.c_float(0.5)), 255)
+
+
+def test_heightfield_tables():
+    hs = hx.HostScene(scene_path("heightfield.hexray"))
+    d = desc_of(hs)
+    f = d.heightfields[0]
+    assert (f.W, f.H, f.max_k, f.use_optimization) == (512, 512, 9, 1)
+    n = f.W * f.H
+    heights = np.ctypeslib.as_array(d.f32_pool, shape=(d.f32_pool_size,))[f.first_height:f.first_height + n].reshape(f.H, f.W)
+    maxh = np.ctypeslib.as_array(d.f32_pool, shape=(d.f32_pool_size,))[f.first_maxh:f.first_maxh + n].reshape(f.H, f.W)
+    high = np.ctypeslib.as_array(d.f32_pool, shape=(d.f32_pool_size,))[f.first_highmap:f.first_highmap + n * 16].reshape(f.H, f.W, 16)
+    # maxH = max over the cell's 2x2 corners (reference src/heightfield.cpp:223-233)
+    pad = np.pad(heights, ((0, 1), (0, 1)), mode="edge")
+    want = np.maximum(np.maximum(pad[:-1, :-1], pad[:-1, 1:]), np.maximum(pad[1:, :-1], pad[1:, 1:]))
+    assert np.array_equal(maxh, want)
+    # the pyramid is monotone in k and bounds the heights (reference src/heightfield.cpp:49-81)
+    assert np.all(high[:, :, 0] >= heights)
+    for k in range(1, f.max_k):
+        assert np.all(high[:, :, k] >= high[:, :, k - 1] - 0)
+    assert f.bbox_min[1] == heights.min() and f.bbox_max[1] == heights.max()
