@@ -191,6 +191,18 @@ def main():
         print(json.dumps(result))
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(scene_name, ov, samples_per_frame):
     """The CPU oracle (a port of the reference's algorithm; oracle/hxo_oracle.c) on this host's cores: the
     workload frame (at reduced resolution when the full frame would take minutes), one warm-up plus repeats
@@ -198,7 +210,7 @@ def cpu_baseline(scene_name, ov, samples_per_frame):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hexray_amd as hx
     from oracle_binding import oracle_lib, oracle_render
-    threads = min(os.cpu_count() or 1, oracle_lib().hxo_max_threads())
+    threads = min(usable_cpus(), oracle_lib().hxo_max_threads())
     ov = dict(ov)
     what = "the whole workload frame"
     if samples_per_frame > 40_000_000:   # e.g. 256 paths per pixel: minutes on a CPU

@@ -216,6 +216,12 @@ def hip_lib():
     if _hip is None:
         if not os.path.exists(HIP_LIB_PATH):
             raise RuntimeError(f"{HIP_LIB_PATH} is missing: run ./build.sh (or __graft_entry__.build()); there is no CPU fallback")
+        # When PyTorch shares the process (bench.py, tests) its bundled HIP runtime must be the one that gets
+        # loaded: two copies of libamdhip64 in one process leave the second without devices.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = ctypes.CDLL(HIP_LIB_PATH)
         lib.hxr_device_count.restype = c_int
         lib.hxr_init.argtypes = [c_int]
