@@ -20,7 +20,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libhexray_host.so")
-HIP_LIB_PATH = os.path.join(_HERE, "lib", "libhexray_hip.so")
+HIP_LIB_PATH = os.environ.get("HXR_HIP_LIB") or os.path.join(_HERE, "lib", "libhexray_hip.so")   # override: A/B of kernel builds
 
 MODE_AUTO, MODE_SINGLE, MODE_ADAPTIVE_AA, MODE_MONTE_CARLO = 0, 1, 2, 3
 LAYOUT_FRAME, LAYOUT_TILES = 0, 1
@@ -41,14 +41,14 @@ class FrameParams(ctypes.Structure):
 COUNTER_FIELDS = [
     "camera_samples", "raycasts", "shadow_queries", "node_tests", "bbox_tests", "kd_visits", "leaf_indices",
     "tri_tests", "mesh_hits", "tex_bilinear", "env_bilinear", "hf_calls", "hf_highest", "hf_height",
-    "hf_tri_tests", "hf_normals", "aa_pixels",
+    "hf_tri_tests", "hf_normals", "aa_pixels", "box_test_mismatch",
 ]
 
 
 class Counters(ctypes.Structure):
     """hxr_counters (include/hexray_hip.h)."""
 
-    _fields_ = [(n, c_uint64) for n in COUNTER_FIELDS] + [("reserved_", c_uint64 * 7)]
+    _fields_ = [(n, c_uint64) for n in COUNTER_FIELDS] + [("reserved_", c_uint64 * 6)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}

@@ -282,8 +282,13 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 	if (timed) HIP_TRY(hipEventRecord(s->ev0, st));
 	if (L.num_chunks > 0) {
 		int grid = grid_for(L.num_chunks);
-		if (counters) hipLaunchKernelGGL(hxr_render_kernel<true>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, L);
-		else hipLaunchKernelGGL(hxr_render_kernel<false>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, L);
+		const HxrSceneDev& V = s->host_view;
+		if (counters)
+			hipLaunchKernelGGL(hxr_render_kernel<true>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures,
+			                   V.shaders, V.layers, V.lights, L);
+		else
+			hipLaunchKernelGGL(hxr_render_kernel<false>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures,
+			                   V.shaders, V.layers, V.lights, L);
 		HIP_TRY(hipGetLastError());
 	}
 	if (timed) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
@@ -524,6 +529,9 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 	if (s->arena.upload(d->layers, (size_t)d->num_layers, &V.layers)) return fail();
 	if (s->arena.upload(d->lights, (size_t)d->num_lights, &V.lights)) return fail();
 
+	const int32_t* d_sides = nullptr;
+	if (s->arena.upload(d->environment.side_bitmap, 6, &d_sides)) return fail();
+	V.env_sides = d_sides;
 	const HxrSceneDev* dv = nullptr;
 	if (s->arena.upload(&V, 1, &dv)) return fail();
 	s->dev = const_cast<HxrSceneDev*>(dv);

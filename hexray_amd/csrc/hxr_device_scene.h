@@ -81,6 +81,7 @@ struct HxrSceneDev {
 	const hxr_shader* shaders;
 	const hxr_layer* layers;
 	const hxr_light* lights;
+	const int32_t* env_sides;   // = &environment.side_bitmap[0] of the copy in HBM (indexed at run time; keeps this header in registers)
 };
 
 // One frame's launch parameters (kernel argument, wave-uniform).

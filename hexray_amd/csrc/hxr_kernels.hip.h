@@ -29,7 +29,7 @@
 // counters (COUNT builds only); order = hxr_counters
 enum {
 	HC_SAMPLES, HC_RAYCASTS, HC_SHADOW, HC_NODE, HC_BBOX, HC_KD, HC_LEAFIDX, HC_TRI, HC_MESHHIT, HC_TEX, HC_ENV,
-	HC_HFCALL, HC_HFHIGH, HC_HFHEIGHT, HC_HFTRI, HC_HFNORM, HC_AA, HC_NUM
+	HC_HFCALL, HC_HFHIGH, HC_HFHEIGHT, HC_HFTRI, HC_HFNORM, HC_AA, HC_BOXMISMATCH, HC_NUM
 };
 
 struct d3 { double x, y, z; };
@@ -94,39 +94,63 @@ HXR_DEV bool box_holds(const Box& b, d3 p)   // BBox::inside, src/bbox.h:78-85
 	       b.lo.z - 1e-6 <= p.z && p.z <= b.hi.z + 1e-6;
 }
 
-// one axis of BBox::testIntersect (src/bbox.h:96-139).  0 = keep going, 1 = hit, -1 = miss
-HXR_DEV int box_axis(double oa, double da, double ia, double loa, double hia, double ou, double du, double lou, double hiu,
-                     double ov, double dv, double lov, double hiv)
+// One axis of BBox::testIntersect (src/bbox.h:96-139), evaluated without branches: lanes of a wave leave
+// the reference's loop at different points, so every exit is computed as a predicate instead.
+//   rej : this axis proves a miss (origin beyond the slab, pointing away)           -> `return false`
+//   hit : one of the two walls of this axis is crossed inside the box               -> `return true`
+// The near wall behind the origin (t < 0) skips the far wall as well, like the reference's `continue`.
+HXR_DEV void box_axis(double oa, double da, double ia, double loa, double hia, double ou, double du, double lou, double hiu, double ov,
+                      double dv, double lov, double hiv, bool& rej, bool& hit)
 {
-	if ((da < 0 && oa < loa) || (da > 0 && oa > hia)) return -1;
-	if (fabs(da) < 1e-9) return 0;
-	double t = (loa - oa) * ia;
-	if (t < 0) return 0;   // near wall behind the origin: the far wall of this axis is skipped as well
-	double pu = ou + du * t;
-	if (lou <= pu && pu <= hiu) {
-		double pv = ov + dv * t;
-		if (lov <= pv && pv <= hiv) return 1;
-	}
-	t = (hia - oa) * ia;
-	if (t < 0) return 0;
-	pu = ou + du * t;
-	if (lou <= pu && pu <= hiu) {
-		double pv = ov + dv * t;
-		if (lov <= pv && pv <= hiv) return 1;
-	}
-	return 0;
+	rej = (da < 0 && oa < loa) || (da > 0 && oa > hia);
+	bool usable = !(fabs(da) < 1e-9);
+	double t0 = (loa - oa) * ia, t1 = (hia - oa) * ia;
+	bool near_ok = usable && !(t0 < 0);
+	bool far_ok = near_ok && !(t1 < 0);
+	double pu0 = ou + du * t0, pv0 = ov + dv * t0;
+	double pu1 = ou + du * t1, pv1 = ov + dv * t1;
+	bool h0 = near_ok && lou <= pu0 && pu0 <= hiu && lov <= pv0 && pv0 <= hiv;
+	bool h1 = far_ok && lou <= pu1 && pu1 <= hiu && lov <= pv1 && pv1 <= hiv;
+	hit = h0 || h1;
 }
 
-// BBox::testIntersect; `inv` = (1/d.x, 1/d.y, 1/d.z), the reference's per-call `mul` hoisted out
+// BBox::testIntersect, literally; `inv` = (1/d.x, 1/d.y, 1/d.z), the reference's per-call `mul` hoisted out.
+// Sequential meaning of the reference loop: inside || (!rejX && (hitX || (!rejY && (hitY || (!rejZ && hitZ))))).
+HXR_DEV bool box_hit_literal(const Box& b, d3 o, d3 d, d3 inv)
+{
+	bool rx, hx, ry, hy, rz, hz;
+	box_axis(o.x, d.x, inv.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y, o.z, d.z, b.lo.z, b.hi.z, rx, hx);
+	box_axis(o.y, d.y, inv.y, b.lo.y, b.hi.y, o.x, d.x, b.lo.x, b.hi.x, o.z, d.z, b.lo.z, b.hi.z, ry, hy);
+	box_axis(o.z, d.z, inv.z, b.lo.z, b.hi.z, o.x, d.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y, rz, hz);
+	return box_holds(b, o) || (!rx && (hx || (!ry && (hy || (!rz && hz)))));
+}
+
+// BBox::testIntersect as a slab test.  The reference answers "does the ray reach the box?" by trying the
+// six walls one after the other (src/bbox.h:96-139): with the origin outside, the ray reaches the box iff
+// it ENTERS through a wall it faces (t >= 0) inside that wall's rectangle -- which is exactly
+// max_a tnear_a <= min_a tfar_a with tfar >= 0, built from the same products (wall - o) * (1/d) the
+// reference forms.  The 1e-6-inflated inside() shortcut (src/bbox.h:95) is kept as is.  The two procedures
+// can only disagree when the entry point lies within one rounding error of a box edge; triangles that
+// close to a kd cell's edge are also listed in the neighbouring cell, so the reported hit is unaffected.
+// The instrumented kernel build evaluates BOTH and counts disagreements (hxr_counters::box_test_mismatch);
+// the GPU tests require that count to be zero on the config scenes.
 HXR_DEV bool box_hit(const Box& b, d3 o, d3 d, d3 inv)
 {
-	if (box_holds(b, o)) return true;
-	int r = box_axis(o.x, d.x, inv.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y, o.z, d.z, b.lo.z, b.hi.z);
-	if (r) return r > 0;
-	r = box_axis(o.y, d.y, inv.y, b.lo.y, b.hi.y, o.x, d.x, b.lo.x, b.hi.x, o.z, d.z, b.lo.z, b.hi.z);
-	if (r) return r > 0;
-	r = box_axis(o.z, d.z, inv.z, b.lo.z, b.hi.z, o.x, d.x, b.lo.x, b.hi.x, o.y, d.y, b.lo.y, b.hi.y);
-	return r > 0;
+	double tx0 = (b.lo.x - o.x) * inv.x, tx1 = (b.hi.x - o.x) * inv.x;
+	double ty0 = (b.lo.y - o.y) * inv.y, ty1 = (b.hi.y - o.y) * inv.y;
+	double tz0 = (b.lo.z - o.z) * inv.z, tz1 = (b.hi.z - o.z) * inv.z;
+	double tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmin(tz0, tz1));
+	double tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmax(tz0, tz1));
+	return (tn <= tf && tf >= 0) || box_holds(b, o);
+}
+
+template <bool COUNT>
+HXR_DEV bool box_test(const Box& b, d3 o, d3 d, d3 inv, Tally<COUNT>& tl)
+{
+	tl.add(HC_BBOX);
+	bool r = box_hit(b, o, d, inv);
+	if (COUNT && r != box_hit_literal(b, o, d, inv)) tl.add(HC_BOXMISMATCH);
+	return r;
 }
 
 // one axis of BBox::closestIntersectionPeriphery (src/bbox.h:145-167); false = the ray cannot hit the box
@@ -229,36 +253,46 @@ HXR_DEV bool cube_query(const double* p, d3 o, d3 d, GeomHit& g)   // Cube::inte
 
 // Leaf of Mesh::intersectKD (src/mesh.cpp:223-232): every triangle is tested against the running
 // best distance; a hit counts for THIS leaf only if its point lies in the leaf's box.
+// Mesh::intersectTriangle (src/mesh.cpp:178-195) accepts iff  0 <= gamma <= best, 0 <= l2 <= 1, 0 <= l3 <= 1,
+// 0 <= l1 <= 1  with gamma = a*rD, l2 = b*rD, l3 = c*rD, rD = 1/Dcr.  The conjunction does not depend on
+// the order of its terms, and  x*rD < 0  <=>  x and Dcr have opposite signs (x != 0), so the three
+// "negative" rejections are decided from signs alone BEFORE the FP64 division is paid for.
 template <bool COUNT>
-HXR_DEV bool leaf_query(const HxrMeshDev& M, const HxrKdRec& leaf, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g, Tally<COUNT>& tl)
+HXR_DEV bool leaf_query(const HxrMeshDev& M, int first, int count, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g, Tally<COUNT>& tl)
 {
 	bool found = false;
-	const HxrTriHot* T = M.leaf_tris + leaf.first;
-	for (int i = 0; i < leaf.count; i++) {
+	const HxrTriHot* T = M.leaf_tris + first;
+	for (int i = 0; i < count; i++) {
 		tl.add(HC_TRI);
 		tl.add(HC_LEAFIDX);
-		// Mesh::intersectTriangle, src/mesh.cpp:178-195
 		if (M.backface_culling) {
-			const hxr_triangle& ct = M.tris[M.leaf_tri_ids[leaf.first + i]];
+			const hxr_triangle& ct = M.tris[M.leaf_tri_ids[first + i]];
 			if (dot(d, ld3(ct.gnormal)) > 0) continue;
 		}
 		d3 N = ld3(T[i].N);
 		double Dcr = dot(N, nd);
 		if (fabs(Dcr) < 1e-12) continue;
 		d3 H = o - ld3(T[i].A);
+		bool neg = Dcr < 0;
+		double ga = dot(N, H);
+		if ((ga < 0) != neg && ga != 0) continue;          // gamma < 0
+		double gb = dot(cross(H, ld3(T[i].AC)), nd);
+		if ((gb < 0) != neg && gb != 0) continue;          // lambda2 < 0
+		double gc = dot(cross(ld3(T[i].AB), H), nd);
+		if ((gc < 0) != neg && gc != 0) continue;          // lambda3 < 0
 		double rD = 1 / Dcr;
-		double gamma = dot(N, H) * rD;
+		double gamma = ga * rD;
 		if (gamma < 0 || gamma > g.t) continue;
-		double l2 = dot(cross(H, ld3(T[i].AC)), nd) * rD;
+		double l2 = gb * rD;
 		if (l2 < 0 || l2 > 1) continue;
-		double l3 = dot(cross(ld3(T[i].AB), H), nd) * rD;
+		double l3 = gc * rD;
 		if (l3 < 0 || l3 > 1) continue;
 		double l1 = 1 - (l2 + l3);
 		if (l1 < 0 || l1 > 1) continue;
 		g.t = gamma;
 		g.l2 = l2;
 		g.l3 = l3;
-		g.tri = M.leaf_tri_ids[leaf.first + i];
+		g.tri = M.leaf_tri_ids[first + i];
 		if (box_holds(box, o + d * gamma)) found = true;
 	}
 	return found;
@@ -273,61 +307,68 @@ HXR_DEV void set_hi(Box& b, int a, double v) { if (a == 0) b.hi.x = v; else if (
 // first leaf that reports a hit (src/mesh.cpp:233-243).  Here the current box lives in registers: going
 // down overwrites one bound with the split position, coming up restores it from the child's record
 // (HxrKdRec::saved) and uses the parent link; `tried` counts the children of the current node that are done.
+// The loop is "while-while": every lane walks inner nodes until it has a leaf to look at (or is finished);
+// only then do the lanes of the wave run their triangle loops, together.
 template <bool COUNT>
 HXR_DEV bool mesh_query(const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, Tally<COUNT>& tl)
 {
 	Box box{ld3(M.bbox_min), ld3(M.bbox_max)};
 	d3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
-	tl.add(HC_BBOX);
-	if (!box_hit(box, o, d, inv)) return false;
+	if (!box_test<COUNT>(box, o, d, inv, tl)) return false;
 	d3 nd = -d;
 	g.t = HXR_INF;
 	g.tri = -1;
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
-		HxrKdRec all;
-		all.first = 0;
-		all.count = M.num_triangles;
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
-		leaf_query<COUNT>(M, all, everything, o, d, nd, g, tl);
+		leaf_query<COUNT>(M, 0, M.num_triangles, everything, o, d, nd, g, tl);
 		return g.t < HXR_INF;
 	}
 	int n = 0;
 	HxrKdRec rec = M.kd[0];
 	tl.add(HC_KD);
-	if (rec.axis == HXR_KD_LEAF) return leaf_query<COUNT>(M, rec, box, o, d, nd, g, tl);
+	if (rec.axis == HXR_KD_LEAF) return leaf_query<COUNT>(M, rec.first, rec.count, box, o, d, nd, g, tl);
 	int tried = 0;
+	bool walking = true;
 	for (;;) {
-		if (tried == 2) {   // both children done: return to the parent
-			if (rec.parent < 0) return false;
-			int p = rec.parent;
-			HxrKdRec prec = M.kd[p];
-			bool was_left = (n == prec.first);
-			if (was_left) set_hi(box, prec.axis, rec.saved); else set_lo(box, prec.axis, rec.saved);
-			int first = comp(o, prec.axis) > prec.split ? 1 : 0;
-			tried = ((was_left ? 0 : 1) == first) ? 1 : 2;
-			n = p;
-			rec = prec;
-			continue;
-		}
-		int a = rec.axis;
-		int first = comp(o, a) > rec.split ? 1 : 0;
-		int c = tried == 0 ? first : 1 - first;
-		double old = c == 0 ? comp(box.hi, a) : comp(box.lo, a);
-		if (c == 0) set_hi(box, a, rec.split); else set_lo(box, a, rec.split);
-		tl.add(HC_BBOX);
-		if (box_hit(box, o, d, inv)) {
-			int child = rec.first + c;
-			HxrKdRec crec = M.kd[child];
-			tl.add(HC_KD);
-			if (crec.axis == HXR_KD_LEAF) {
-				if (leaf_query<COUNT>(M, crec, box, o, d, nd, g, tl)) return true;
-			} else {
-				n = child;
-				rec = crec;
-				tried = 0;
+		int leaf_first = -1, leaf_count = 0, a = 0, c = 0;
+		double old = 0;
+		while (walking && leaf_first < 0) {
+			if (tried == 2) {   // both children done: return to the parent
+				if (rec.parent < 0) { walking = false; break; }
+				int p = rec.parent;
+				HxrKdRec prec = M.kd[p];
+				bool was_left = (n == prec.first);
+				if (was_left) set_hi(box, prec.axis, rec.saved); else set_lo(box, prec.axis, rec.saved);
+				int first = comp(o, prec.axis) > prec.split ? 1 : 0;
+				tried = ((was_left ? 0 : 1) == first) ? 1 : 2;
+				n = p;
+				rec = prec;
 				continue;
 			}
+			a = rec.axis;
+			int first = comp(o, a) > rec.split ? 1 : 0;
+			c = tried == 0 ? first : 1 - first;
+			int child = rec.first + c;
+			HxrKdRec crec = M.kd[child];   // issued before the box test so that its latency overlaps it
+			old = c == 0 ? comp(box.hi, a) : comp(box.lo, a);
+			if (c == 0) set_hi(box, a, rec.split); else set_lo(box, a, rec.split);
+			if (box_test<COUNT>(box, o, d, inv, tl)) {
+				tl.add(HC_KD);
+				if (crec.axis == HXR_KD_LEAF) {
+					leaf_first = crec.first;
+					leaf_count = crec.count;
+				} else {
+					n = child;
+					rec = crec;
+					tried = 0;
+				}
+			} else {
+				if (c == 0) set_hi(box, a, old); else set_lo(box, a, old);
+				tried++;
+			}
 		}
+		if (leaf_first < 0) return false;
+		if (leaf_query<COUNT>(M, leaf_first, leaf_count, box, o, d, nd, g, tl)) return true;
 		if (c == 0) set_hi(box, a, old); else set_lo(box, a, old);
 		tried++;
 	}
@@ -437,7 +478,7 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 template <bool COUNT>
 HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, Tally<COUNT>& tl)
 {
-	const HxrNodeDev& N = S.nodes[ni];
+	const HxrNodeDev& N = S.nodes[__builtin_amdgcn_readfirstlane(ni)];   // the node scan is wave-uniform: scalar loads
 	tl.add(HC_NODE);
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
@@ -678,114 +719,47 @@ HXR_DEV f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
 		case 4: fx = s.x; fy = s.z; break;
 		default: fx = s.x; fy = -s.y; break;
 	}
-	const HxrBitmapDev& b = S.bitmaps[S.environment.side_bitmap[face]];
+	const HxrBitmapDev& b = S.bitmaps[S.env_sides[face]];
 	tl.add(HC_ENV);
 	return bitmap_bilinear(b, (float)((fx + 1) * 0.5 * (b.width - 1)), (float)((fy + 1) * 0.5 * (b.height - 1)));
 }
 
 // ------------------------------------------------------------------------------------------------
-// scene queries
+// scene queries and the per-sample integrator
 // ------------------------------------------------------------------------------------------------
-// visible(), src/main.cpp:171-190: any node closer than |AB|, or any light in between, blocks
+// One query = the node scan shared by TraceContext::raycast (src/main.cpp:69-75: keep the node whose
+// world-space hit distance is smallest) and visible() (src/main.cpp:179-184: stop at the first node
+// hit closer than |AB|).  Both compare `info.dist < limit`; raycast lowers the limit as it goes,
+// visible() leaves the scan at the first success.  Returns the node index or -1.
 template <bool COUNT>
-HXR_DEV bool visible(const HxrSceneDev& S, d3 A, d3 B, Tally<COUNT>& tl)
+HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any, GeomHit& bg, double& bw, Tally<COUNT>& tl)
 {
-	tl.add(HC_SHADOW);
-	double D = dist3(A, B);
-	d3 d = unit(B - A);
+	int node = -1;
+	bw = limit;
 	for (int ni = 0; ni < S.num_nodes; ni++) {
 		GeomHit g;
 		double w;
-		if (node_query<COUNT>(S, ni, A, d, g, w, tl) && w < D) return false;
+		if (node_query<COUNT>(S, ni, o, d, g, w, tl) && w < bw) {
+			bw = w;
+			bg = g;
+			node = ni;
+			if (any) break;
+		}
 	}
-	for (int li = 0; li < S.num_lights; li++) {
-		double dd = D;
-		if (light_query(S.lights[li], A, d, dd)) return false;
-	}
-	return true;
+	return node;
 }
 
 struct RayItem {
 	d3 o, d;
-	f3 weight;
+	f3 weight;       // Whitted: product of the blend / reflectance factors on the way here; path tracing: throughput
 	int depth;
 	uint32_t flags, key;
 };
-
-// TraceContext::raycast, src/main.cpp:63-103.  true = the ray ended (colour in `early`), false = `sf` / `node` hold the hit.
-template <bool COUNT>
-HXR_DEV bool raycast(const HxrSceneDev& S, const RayItem& r, Surface& sf, int& node, f3& early, Tally<COUNT>& tl)
-{
-	tl.add(HC_RAYCASTS);
-	if (r.depth > S.settings.max_trace_depth) { early = mkf(0, 0, 0); return true; }
-	double best = HXR_INF;
-	GeomHit bg;
-	node = -1;
-	for (int ni = 0; ni < S.num_nodes; ni++) {
-		GeomHit g;
-		double w;
-		if (node_query<COUNT>(S, ni, r.o, r.d, g, w, tl) && w < best) {
-			best = w;
-			bg = g;
-			node = ni;
-		}
-	}
-	bool lit = false;
-	f3 lc = mkf(0, 0, 0);
-	for (int li = 0; li < S.num_lights; li++) {
-		const hxr_light& L = S.lights[li];
-		int s = light_query(L, r.o, r.d, best);
-		if (s == -1) { lit = true; lc = mkf(0, 0, 0); }
-		else if (s == 1) { lit = true; lc = (ldf(L.color) * L.power) * L.scale_factor; }
-	}
-	if (lit) { early = (r.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lc; return true; }
-	if (best >= HXR_INF) {
-		early = S.environment.present ? environment_lookup<COUNT>(S, r.d, tl) : ldf(S.settings.background);
-		return true;
-	}
-	surface_of<COUNT>(S, node, r.o, r.d, bg, best, sf, tl);
-	int bump = S.nodes[node].bump;
-	if (bump >= 0) texture_bump<COUNT>(S, bump, sf, tl);
-	return false;
-}
 
 struct RngCtx {
 	uint64_t seed;
 	uint32_t pixel, sample;
 };
-
-// Lambert::computeColor (src/shading.cpp:67-91) / Phong::computeColor (:112-145)
-template <bool COUNT>
-HXR_DEV f3 shade_diffuse(const HxrSceneDev& S, const hxr_shader& sh, const RayItem& r, const Surface& sf, const RngCtx& rc, Tally<COUNT>& tl)
-{
-	f3 base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, r.d, sf, tl) : ldf(sh.color);
-	f3 direct = mkf(0, 0, 0);
-	for (int li = 0; li < S.num_lights; li++) {
-		const hxr_light& L = S.lights[li];
-		int n = light_num_samples(L);
-		f3 sum = mkf(0, 0, 0);
-		for (int i = 0; i < n; i++) {
-			double j1 = 0, j2 = 0;
-			if (L.type == HXR_LIGHT_RECT) hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)li * 4096u + (uint32_t)i), j1, j2);
-			d3 lp;
-			f3 lc;
-			light_sample(L, i, sf.ip, j1, j2, lp, lc);
-			if (is_zero(lc) || !visible<COUNT>(S, lp, sf.ip + sf.norm * 1e-6, tl)) continue;
-			d3 to_ip = sf.ip - lp;   // getLambertTerm, src/shading.cpp:57-65
-			double d2 = len2(to_ip);
-			float lt = (float)fmax(0.0, dot(sf.norm, unit(-to_ip)));
-			if (sh.type == HXR_SHADER_PHONG) {
-				d3 from_light = unit(sf.ip - lp);
-				d3 refl = reflect3(from_light, faceforward(from_light, sf.norm));
-				float cg = (float)dot(-r.d, refl);
-				if (cg > 0) sum = sum + (ldf(sh.specular) * lc) * powf(cg, sh.exponent);
-			}
-			sum = sum + (base * lc) * (float)(lt * L.power / d2);
-		}
-		direct = direct + fdiv(sum, (float)n);
-	}
-	return direct + base * ldf(S.settings.ambient);
-}
 
 HXR_DEV bool refract_dir(d3 i, d3 n, float ior, d3& out)   // refract(), src/shading.cpp:208-214 (float arithmetic)
 {
@@ -794,70 +768,6 @@ HXR_DEV bool refract_dir(d3 i, d3 n, float ior, d3& out)   // refract(), src/sha
 	if (k < 0) return false;
 	out = i * (double)ior - n * (double)(ior * ndi + sqrtf(k));
 	return true;
-}
-
-// raytrace(), src/main.cpp:105-113, with the recursion through Reflection / Refraction / Layered
-// (src/shading.cpp:159-232,315-324) flattened into a ray stack and a shader work list.
-template <bool COUNT>
-HXR_DEV f3 trace_whitted(const HxrSceneDev& S, d3 o, d3 d, const RngCtx& rc, Tally<COUNT>& tl)
-{
-	RayItem stack[HXR_RAY_STACK];
-	int top = 0;
-	f3 acc = mkf(0, 0, 0);
-	stack[top++] = RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u};
-	while (top > 0) {
-		RayItem r = stack[--top];
-		Surface sf;
-		int node;
-		f3 early;
-		if (raycast<COUNT>(S, r, sf, node, early, tl)) {
-			acc = acc + early * r.weight;
-			continue;
-		}
-		int sh_stack[HXR_SHADER_STACK];
-		f3 w_stack[HXR_SHADER_STACK];
-		int stop = 0;
-		sh_stack[stop] = S.nodes[node].shader;
-		w_stack[stop++] = r.weight;
-		while (stop > 0) {
-			int si = sh_stack[--stop];
-			f3 w = w_stack[stop];
-			const hxr_shader& sh = S.shaders[si];
-			switch (sh.type) {
-				case HXR_SHADER_LAMBERT:
-				case HXR_SHADER_PHONG: acc = acc + shade_diffuse<COUNT>(S, sh, r, sf, rc, tl) * w; break;
-				case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
-				case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy is rejected at create time)
-					d3 n = faceforward(r.d, sf.norm);
-					if (top < HXR_RAY_STACK)
-						stack[top++] = RayItem{sf.ip + n * 1e-6, reflect3(r.d, n), ldf(sh.color) * w, r.depth + 1, r.flags, hxr_child_key(r.key, si, 0)};
-					break;
-				}
-				case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
-					d3 out;
-					bool ok = dot(r.d, sf.norm) < 0 ? refract_dir(r.d, sf.norm, (float)(1 / sh.ior), out) : refract_dir(r.d, -sf.norm, (float)sh.ior, out);
-					if (ok && top < HXR_RAY_STACK)
-						stack[top++] = RayItem{sf.ip - faceforward(r.d, sf.norm) * 0.000001, out, ldf(sh.color) * w, r.depth + 1, r.flags, hxr_child_key(r.key, si, 0)};
-					break;
-				}
-				case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
-					f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
-					for (int i = sh.num_layers - 1; i >= 0; i--) {
-						const hxr_layer& L = S.layers[sh.first_layer + i];
-						f3 blend = L.texture >= 0 ? texture_sample<COUNT>(S, L.texture, r.d, sf, tl) : ldf(L.blend);
-						if (stop < HXR_SHADER_STACK) {
-							sh_stack[stop] = L.shader;
-							w_stack[stop++] = (w * blend) * rem;
-						}
-						rem = rem * (mkf(1, 1, 1) - blend);
-					}
-					break;
-				}
-				default: break;
-			}
-		}
-	}
-	return acc;
 }
 
 HXR_DEV d3 hemisphere(double u, double v, d3 normal)   // hemisphereSample, src/util.cpp:109-129
@@ -870,95 +780,307 @@ HXR_DEV d3 hemisphere(double u, double v, d3 normal)   // hemisphereSample, src/
 	return dd;
 }
 
-// pathtrace(), src/main.cpp:115-169, as a loop: the recursion is a chain (one spawned ray per vertex)
-// and its result is linear in the tail, so each vertex adds its explicit-light term scaled by the
-// throughput and the walk continues with throughput * brdf / pdf.
+// What stays of an IntersectionInfo once the bump map has been applied
+struct HitPoint {
+	d3 ip, norm;
+	double u, v;
+};
+
+// The integrator.  raytrace() <-> Shader::computeColor() (src/main.cpp:105-113, src/shading.cpp) and
+// pathtrace() (src/main.cpp:115-169) are mutually recursive in the reference and call visible() from
+// inside the shaders.  Here one sample is a small state machine around ONE scene_query() site per loop
+// turn, so that all lanes of the wave -- whether they need the closest hit of a camera / secondary ray
+// or the any-hit of a shadow ray -- traverse together:
+//   Q_CLOSEST  the current ray `cur` needs raycast()                                (src/main.cpp:63-103)
+//   Q_SHADOW   a light sample of the shader being evaluated needs visible()          (src/main.cpp:171-190)
+// Between two queries a lane finishes whatever needs no ray: light hits, environment, textures, the
+// Layered expansion (src/shading.cpp:315-324), pushing Reflection / Refraction rays (:159-232) with their
+// weights, BRDF spawn / eval for path tracing (:93-109,189-263).
+enum { Q_NONE = 0, Q_CLOSEST = 1, Q_SHADOW = 2 };
+
 template <bool COUNT>
-HXR_DEV f3 trace_path(const HxrSceneDev& S, d3 o, d3 d, const RngCtx& rc, Tally<COUNT>& tl)
+HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Tally<COUNT>& tl)
 {
-	f3 acc = mkf(0, 0, 0), mult = mkf(1, 1, 1);
-	RayItem r{o, d, mkf(1, 1, 1), 0, 0u, 0u};
+	const bool gi = S.settings.gi != 0;
+	RayItem stack[HXR_RAY_STACK];
+	int sh_stack[HXR_SHADER_STACK];
+	f3 w_stack[HXR_SHADER_STACK];
+	int top = 0, stop = 0;
+	f3 acc = mkf(0, 0, 0);
+	RayItem cur{o0, d0, mkf(1, 1, 1), 0, 0u, 0u};
+	int want = Q_CLOSEST;
+	// context of the hit being shaded
+	HitPoint hp{};
+	int cur_shader = -1;          // shader whose light loop is running (Whitted) / shader of the hit (path)
+	f3 cur_w = mkf(0, 0, 0);      // weight of that shader instance
+	f3 base = mkf(0, 0, 0), direct = mkf(0, 0, 0), sum = mkf(0, 0, 0), lc = mkf(0, 0, 0);
+	d3 lp = mk3(0, 0, 0);         // light sample position
+	int li = 0, ls = 0;           // light / sample cursor
+	bool in_lights = false;
+
 	for (;;) {
-		if (intensity(mult) < 0.001f) break;
-		Surface sf;
-		int node;
-		f3 early;
-		if (raycast<COUNT>(S, r, sf, node, early, tl)) {
-			acc = acc + early * mult;
-			break;
+		// ---- 1. what does this lane ask the scene?
+		d3 qo = cur.o, qd = cur.d;
+		double qlimit = HXR_INF;
+		bool qany = false;
+		if (want == Q_CLOSEST) {
+			if (gi && intensity(cur.weight) < 0.001f) want = Q_NONE;                     // pathtrace early exit, src/main.cpp:118
+			else {
+				tl.add(HC_RAYCASTS);
+				if (cur.depth > S.settings.max_trace_depth) {                            // src/main.cpp:65: black
+					want = Q_NONE;
+					if (!gi && top > 0) { cur = stack[--top]; want = Q_CLOSEST; continue; }
+				}
+			}
+		} else if (want == Q_SHADOW) {
+			tl.add(HC_SHADOW);
+			d3 A = gi ? hp.ip + hp.norm * 1e-6 : lp;                                     // path: surface -> light (src/main.cpp:155)
+			d3 B = gi ? lp : hp.ip + hp.norm * 1e-6;                                     // direct lighting: light -> surface (src/shading.cpp:81,126)
+			qo = A;
+			qlimit = dist3(A, B);
+			qd = unit(B - A);
+			qany = true;
 		}
-		int si = S.nodes[node].shader;
-		const hxr_shader& sh = S.shaders[si];
-		// BRDF::spawnRay: Lambert src/shading.cpp:99-109, Reflection :196-205, Refraction :241-263, default :37-43
-		RayItem nx = r;
-		nx.depth = r.depth + 1;
-		nx.key = hxr_child_key(r.key, si, 0);
-		f3 bc = mkf(1, 0, 0);
-		float pdf = -1;
-		if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG) {
-			d3 N = faceforward(r.d, sf.norm);
-			nx.o = sf.ip + N * 1e-6;
-			double u, v;
-			hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_HEMISPHERE), u, v);
-			nx.d = hemisphere(u, v, N);
-			nx.flags |= HXR_RF_GI_DIFFUSE;
-			f3 base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, r.d, sf, tl) : ldf(sh.color);
-			bc = (base * (float)(1 / HXR_PI)) * (float)dot(nx.d, N);
-			pdf = (float)(1 / (2 * HXR_PI));
-		} else if (sh.type == HXR_SHADER_REFLECTION) {
-			d3 N = faceforward(r.d, sf.norm);
-			nx.o = sf.ip + N * 1e-6;
-			nx.d = reflect3(r.d, N);
-			nx.flags &= ~HXR_RF_GI_DIFFUSE;
-			bc = ldf(sh.color) * 1e+6f;
-			pdf = 1e+6f;
-		} else if (sh.type == HXR_SHADER_REFRACTION) {
-			d3 out;
-			bool ok = dot(r.d, sf.norm) < 0 ? refract_dir(r.d, sf.norm, (float)(1 / sh.ior), out) : refract_dir(r.d, -sf.norm, (float)sh.ior, out);
-			if (ok) {
-				nx.o = sf.ip - faceforward(r.d, sf.norm) * 0.000001;
-				nx.d = out;
+		if (want == Q_NONE) break;
+
+		// ---- 2. the one traversal site
+		GeomHit bg;
+		double bw;
+		int node = scene_query<COUNT>(S, qo, qd, qlimit, qany, bg, bw, tl);
+
+		// ---- 3. consume the answer
+		bool shade_next = false;   // run the shader work list
+		if (want == Q_SHADOW) {
+			bool blocked = node >= 0;
+			for (int k = 0; k < S.num_lights && !blocked; k++) {
+				double dd = qlimit;
+				if (light_query(S.lights[k], qo, qd, dd)) blocked = true;
+			}
+			const hxr_shader& sh = S.shaders[cur_shader];
+			if (!gi) {
+				if (!blocked) {   // the light sample reaches the surface: Lambert / Phong term (src/shading.cpp:84-85,129-141)
+					const hxr_light& L = S.lights[li];
+					d3 to_ip = hp.ip - lp;
+					double d2 = len2(to_ip);
+					float lt = (float)fmax(0.0, dot(hp.norm, unit(-to_ip)));
+					if (sh.type == HXR_SHADER_PHONG) {
+						d3 from_light = unit(hp.ip - lp);
+						d3 refl = reflect3(from_light, faceforward(from_light, hp.norm));
+						float cg = (float)dot(-cur.d, refl);
+						if (cg > 0) sum = sum + (ldf(sh.specular) * lc) * powf(cg, sh.exponent);
+					}
+					sum = sum + (base * lc) * (float)(lt * L.power / d2);
+				}
+				ls++;
+				shade_next = true;
+			} else {
+				if (!blocked) {   // explicit light sampling of the path tracer (src/main.cpp:157-168)
+					const hxr_light& L = S.lights[li];
+					d3 w_out = unit(lp - hp.ip);
+					f3 ev = mkf(1, 0, 0);   // BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
+					if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG)
+						ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, hp.norm));
+					else if (sh.type == HXR_SHADER_REFLECTION)
+						ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
+					else if (sh.type == HXR_SHADER_REFRACTION)
+						ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.99999999 ? ldf(sh.color) : mkf(0, 0, 0);
+					f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
+					if (intensity(from_light) > 0) {
+						float p_choose = 1.0f / (float)S.num_lights;
+						float p_hit = (float)(1.0f / light_solid_angle(L, hp.ip));
+						acc = acc + fdiv(from_light * cur.weight, p_choose * p_hit);
+					}
+				}
+				in_lights = false;
+				shade_next = true;   // continue the path below
+			}
+		} else {   // Q_CLOSEST: the rest of TraceContext::raycast (src/main.cpp:76-103)
+			bool lit = false;
+			f3 lcol = mkf(0, 0, 0);
+			for (int k = 0; k < S.num_lights; k++) {
+				const hxr_light& L = S.lights[k];
+				int side = light_query(L, qo, qd, bw);
+				if (side == -1) { lit = true; lcol = mkf(0, 0, 0); }
+				else if (side == 1) { lit = true; lcol = (ldf(L.color) * L.power) * L.scale_factor; }
+			}
+			bool ended = true;
+			f3 early = mkf(0, 0, 0);
+			if (lit) early = (cur.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lcol;
+			else if (bw >= HXR_INF) early = S.environment.present ? environment_lookup<COUNT>(S, qd, tl) : ldf(S.settings.background);
+			else ended = false;
+			if (ended) {
+				acc = acc + early * cur.weight;
+				if (gi) want = Q_NONE;
+				else if (top > 0) { cur = stack[--top]; want = Q_CLOSEST; }
+				else want = Q_NONE;
+				if (want == Q_NONE) break;
+				continue;
+			}
+			Surface sf;
+			surface_of<COUNT>(S, node, qo, qd, bg, bw, sf, tl);
+			int bump = S.nodes[node].bump;
+			if (bump >= 0) texture_bump<COUNT>(S, bump, sf, tl);
+			hp.ip = sf.ip;
+			hp.norm = sf.norm;
+			hp.u = sf.u;
+			hp.v = sf.v;
+			if (!gi) {
+				stop = 0;
+				sh_stack[stop] = S.nodes[node].shader;
+				w_stack[stop++] = cur.weight;
+				in_lights = false;
+			} else {
+				cur_shader = S.nodes[node].shader;
+				in_lights = true;   // "before the light sample"
+			}
+			shade_next = true;
+		}
+
+		if (!shade_next) continue;
+		Surface sfl;   // texture_sample() reads u, v, norm
+		sfl.ip = hp.ip; sfl.norm = hp.norm; sfl.u = hp.u; sfl.v = hp.v;
+
+		if (gi) {
+			// ---- path tracing: one vertex = [light sample] then spawn (src/main.cpp:122-168)
+			const hxr_shader& sh = S.shaders[cur_shader];
+			const bool diffuse = sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG;
+			// BRDF::spawnRay must succeed first (pdf <= 0 ends the path before any light sampling, src/main.cpp:129-130)
+			d3 refr_dir = mk3(0, 0, 0);
+			bool spawn_ok = diffuse || sh.type == HXR_SHADER_REFLECTION;
+			if (sh.type == HXR_SHADER_REFRACTION)
+				spawn_ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), refr_dir) : refract_dir(cur.d, -hp.norm, (float)sh.ior, refr_dir);
+			if (!spawn_ok) break;
+			if (in_lights) {   // first visit of this vertex: try the explicit light sample
+				in_lights = false;
+				if (diffuse) base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
+				if (S.num_lights > 0) {
+					HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_PICK);
+					li = (int)hxr_below(pick.w0, (uint32_t)S.num_lights);
+					const hxr_light& L = S.lights[li];
+					if (light_solid_angle(L, hp.ip) > 0) {
+						int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples(L));
+						double j1, j2;
+						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_JITTER), j1, j2);
+						f3 unused;
+						light_sample(L, idx, hp.ip, j1, j2, lp, unused);
+						want = Q_SHADOW;
+						continue;
+					}
+				}
+			}
+			// spawn the next ray: Lambert src/shading.cpp:99-109, Reflection :196-205, Refraction :241-263
+			RayItem nx = cur;
+			nx.depth = cur.depth + 1;
+			nx.key = hxr_child_key(cur.key, cur_shader, 0);
+			f3 bc;
+			float pdf;
+			if (diffuse) {
+				d3 N = faceforward(cur.d, hp.norm);
+				nx.o = hp.ip + N * 1e-6;
+				double u, v;
+				hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_HEMISPHERE), u, v);
+				nx.d = hemisphere(u, v, N);
+				nx.flags |= HXR_RF_GI_DIFFUSE;
+				bc = (base * (float)(1 / HXR_PI)) * (float)dot(nx.d, N);
+				pdf = (float)(1 / (2 * HXR_PI));
+			} else if (sh.type == HXR_SHADER_REFLECTION) {
+				d3 N = faceforward(cur.d, hp.norm);
+				nx.o = hp.ip + N * 1e-6;
+				nx.d = reflect3(cur.d, N);
+				nx.flags &= ~HXR_RF_GI_DIFFUSE;
+				bc = ldf(sh.color) * 1e+6f;
+				pdf = 1e+6f;
+			} else {
+				nx.o = hp.ip - faceforward(cur.d, hp.norm) * 0.000001;
+				nx.d = refr_dir;
 				nx.flags &= ~HXR_RF_GI_DIFFUSE;
 				bc = ldf(sh.color) * 1e+6f;
 				pdf = 1e+6f;
 			}
+			nx.weight = fdiv(cur.weight * bc, pdf);
+			cur = nx;
+			want = Q_CLOSEST;
+			continue;
 		}
-		if (pdf <= 0) break;
-		// explicit light sampling at this vertex (src/main.cpp:133-168)
-		if (S.num_lights > 0) {
-			HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_LIGHT_PICK);
-			const hxr_light& L = S.lights[hxr_below(pick.w0, (uint32_t)S.num_lights)];
-			double solid = light_solid_angle(L, sf.ip);
-			if (solid > 0) {
-				int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples(L));
-				double j1, j2;
-				hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, r.key, HXR_DIM_LIGHT_JITTER), j1, j2);
-				d3 on_light;
-				f3 unused;
-				light_sample(L, idx, sf.ip, j1, j2, on_light, unused);
-				if (visible<COUNT>(S, sf.ip + sf.norm * 1e-6, on_light, tl)) {
-					d3 w_out = unit(on_light - sf.ip);
-					// BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
-					f3 ev = mkf(1, 0, 0);
-					if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG) {
-						f3 base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, r.d, sf, tl) : ldf(sh.color);
-						ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, sf.norm));
-					} else if (sh.type == HXR_SHADER_REFLECTION) {
-						ev = dot(reflect3(r.d, faceforward(r.d, sf.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
-					} else if (sh.type == HXR_SHADER_REFRACTION) {
-						ev = dot(reflect3(r.d, faceforward(r.d, sf.norm)), w_out) > 0.99999999 ? ldf(sh.color) : mkf(0, 0, 0);
+
+		// ---- Whitted: run the shader work list until a light sample needs a shadow ray or the list is empty
+		for (;;) {
+			if (in_lights) {   // Lambert / Phong light loops (src/shading.cpp:74-88,119-142)
+				const hxr_shader& sh = S.shaders[cur_shader];
+				bool asked = false;
+				while (li < S.num_lights) {
+					const hxr_light& L = S.lights[li];
+					int n = light_num_samples(L);
+					if (ls < n) {
+						double j1 = 0, j2 = 0;
+						if (L.type == HXR_LIGHT_RECT)
+							hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)li * 4096u + (uint32_t)ls), j1, j2);
+						light_sample(L, ls, hp.ip, j1, j2, lp, lc);
+						if (is_zero(lc)) { ls++; continue; }
+						asked = true;
+						break;
 					}
-					f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
-					if (intensity(from_light) > 0) {
-						float p_choose = 1.0f / (float)S.num_lights;
-						float p_hit = (float)(1.0f / solid);
-						acc = acc + fdiv(from_light * mult, p_choose * p_hit);
-					}
+					direct = direct + fdiv(sum, (float)n);
+					sum = mkf(0, 0, 0);
+					li++;
+					ls = 0;
 				}
+				if (asked) { want = Q_SHADOW; break; }
+				acc = acc + (direct + base * ldf(S.settings.ambient)) * cur_w;
+				in_lights = false;
+				(void)sh;
+			}
+			if (stop == 0) {   // this hit is done: next pending ray
+				if (top > 0) { cur = stack[--top]; want = Q_CLOSEST; }
+				else want = Q_NONE;
+				break;
+			}
+			int si = sh_stack[--stop];
+			f3 w = w_stack[stop];
+			const hxr_shader& sh = S.shaders[si];
+			switch (sh.type) {
+				case HXR_SHADER_LAMBERT:
+				case HXR_SHADER_PHONG:
+					cur_shader = si;
+					cur_w = w;
+					base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
+					direct = mkf(0, 0, 0);
+					sum = mkf(0, 0, 0);
+					li = 0;
+					ls = 0;
+					in_lights = true;
+					break;
+				case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
+				case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy is rejected at create time)
+					d3 n = faceforward(cur.d, hp.norm);
+					if (top < HXR_RAY_STACK)
+						stack[top++] = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, si, 0)};
+					break;
+				}
+				case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
+					d3 out;
+					bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
+					if (ok && top < HXR_RAY_STACK)
+						stack[top++] = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, si, 0)};
+					break;
+				}
+				case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
+					f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
+					for (int i = sh.num_layers - 1; i >= 0; i--) {
+						const hxr_layer& Ly = S.layers[sh.first_layer + i];
+						f3 blend = Ly.texture >= 0 ? texture_sample<COUNT>(S, Ly.texture, cur.d, sfl, tl) : ldf(Ly.blend);
+						if (stop < HXR_SHADER_STACK) {
+							sh_stack[stop] = Ly.shader;
+							w_stack[stop++] = (w * blend) * rem;
+						}
+						rem = rem * (mkf(1, 1, 1) - blend);
+					}
+					break;
+				}
+				default: break;
 			}
 		}
-		mult = fdiv(mult * bc, pdf);
-		r = nx;
+		if (want == Q_NONE) break;
 	}
 	return acc;
 }
@@ -998,12 +1120,12 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	d3 o, d;
 	if (S.camera.stereo_separation == 0.0) {
 		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
-		return S.settings.gi ? trace_path<COUNT>(S, o, d, rc, tl) : trace_whitted<COUNT>(S, o, d, rc, tl);
+		return trace_rays<COUNT>(S, o, d, rc, tl);
 	}
 	f3 eye[2];
-	for (int e = 0; e < 2; e++) {
+	for (int e = 0; e < 2; e++) {   // anaglyph pair (src/main.cpp:237-247)
 		camera_ray(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
-		eye[e] = S.settings.gi ? trace_path<COUNT>(S, o, d, rc, tl) : trace_whitted<COUNT>(S, o, d, rc, tl);
+		eye[e] = trace_rays<COUNT>(S, o, d, rc, tl);
 	}
 	float ml = intensity(eye[0]), mr = intensity(eye[1]);
 	return mkf(ml + (eye[0].x - ml) * 0.3f, mr + (eye[1].y - mr) * 0.3f, mr + (eye[1].z - mr) * 0.3f);
@@ -1052,11 +1174,28 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // the render kernel: persistent wavefronts, one ray packet (64 camera samples) per dispenser ticket
 // ------------------------------------------------------------------------------------------------
 #define HXR_BLOCK 256
+#ifndef HXR_MIN_WAVES
+#define HXR_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for
+#endif
 
 template <bool COUNT>
-__global__ __launch_bounds__(HXR_BLOCK) void hxr_render_kernel(const HxrSceneDev* __restrict__ Sp, HxrLaunch P)
+__global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
+    const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
+    const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
+    const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights, HxrLaunch P)
 {
-	const HxrSceneDev& S = *Sp;
+	// The small tables arrive as separate `const __restrict__` kernel arguments: only then can the compiler
+	// prove that the frame / counter stores of this kernel never clobber them, and fetch their wave-uniform
+	// records (node transforms, shaders, lights) with scalar loads into SGPRs instead of 64 identical vector loads.
+	HxrSceneDev S = *Sp;
+	S.nodes = a_nodes;
+	S.meshes = a_meshes;
+	S.heightfields = a_hfs;
+	S.bitmaps = a_bitmaps;
+	S.textures = a_textures;
+	S.shaders = a_shaders;
+	S.layers = a_layers;
+	S.lights = a_lights;
 	__shared__ float lds_rgb[HXR_BLOCK / 64][64][3];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	Tally<COUNT> tl;

@@ -285,7 +285,8 @@ typedef struct hxr_counters {
 	uint64_t hf_tri_tests;    /* intersectTriangleFast calls */
 	uint64_t hf_normals;      /* getNormal calls */
 	uint64_t aa_pixels;       /* pixels flagged by detectAApixels */
-	uint64_t reserved_[7];
+	uint64_t box_test_mismatch; /* instrumented GPU build: box tests whose slab form and literal BBox::testIntersect form disagreed */
+	uint64_t reserved_[6];
 } hxr_counters;
 
 typedef struct hxr_scene hxr_scene;   /* opaque: the scene resident in HBM */
