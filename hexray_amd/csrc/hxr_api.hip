@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "hexray_hip.h"
@@ -146,13 +147,18 @@ int validate(const hxr_scene_desc* d)
 	return 0;
 }
 
-// kd records: parent link + the bound each node overrides (see hxr_device_scene.h)
-void build_kd_records(const hxr_scene_desc* d, const hxr_mesh& m, std::vector<HxrKdRec>& recs, std::vector<HxrTriHot>& hot, std::vector<int32_t>& ids)
+// Wide kd records (node box stored in the node) + leaf-ordered hot triangles of one mesh, appended to the
+// scene-wide arrays (see hxr_device_scene.h)
+void append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdWide>& kd, std::vector<HxrTriHot>& hot,
+                        std::vector<int32_t>& ids)
 {
 	const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
 	const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
 	const hxr_triangle* tris = d->triangles + m.first_triangle;
 	const double* verts = d->f64_pool + m.first_vertex * 3;
+	o.kd_first = (int32_t)kd.size();
+	o.hot_first = (int32_t)hot.size();
+	const size_t hot0 = hot.size();
 	auto push_hot = [&](int ti) {
 		const hxr_triangle& t = tris[ti];
 		HxrTriHot h;
@@ -169,35 +175,32 @@ void build_kd_records(const hxr_scene_desc* d, const hxr_mesh& m, std::vector<Hx
 		for (int64_t i = 0; i < m.num_triangles; i++) push_hot((int)i);
 		return;
 	}
-	recs.resize((size_t)m.num_kd_nodes);
+	const size_t kd0 = kd.size();
+	kd.resize(kd0 + (size_t)m.num_kd_nodes);
 	struct Item { int node; double lo[3], hi[3]; };
 	std::vector<Item> todo;
 	Item root;
 	root.node = 0;
 	for (int c = 0; c < 3; c++) { root.lo[c] = m.bbox_min[c]; root.hi[c] = m.bbox_max[c]; }
-	recs[0].saved = 0;
 	todo.push_back(root);
 	while (!todo.empty()) {
 		Item it = todo.back();
 		todo.pop_back();
 		const hxr_kd_node& n = nodes[it.node];
-		HxrKdRec& r = recs[(size_t)it.node];
+		HxrKdWide& r = kd[kd0 + (size_t)it.node];
+		for (int c = 0; c < 3; c++) { r.lo[c] = it.lo[c]; r.hi[c] = it.hi[c]; }
 		r.split = n.split;
-		r.parent = n.parent;
-		r.axis = n.axis;
 		if (n.axis == HXR_KD_LEAF) {
-			r.first = (int32_t)hot.size();
-			r.count = n.count;
+			r.first = (int32_t)(hot.size() - hot0);
+			r.axis_count = HXR_KD_LEAF | (n.count << 2);
 			for (int i = 0; i < n.count; i++) push_hot(leaf_idx[n.first + i]);
 			continue;
 		}
 		r.first = n.first;
-		r.count = 0;
-		Item L = it, R = it;
+		r.axis_count = n.axis;
+		Item L = it, R = it;   // BBox::split: the children copy the box and replace one bound by the split position
 		L.node = n.first;
 		R.node = n.first + 1;
-		recs[(size_t)L.node].saved = it.hi[n.axis];   // the left child's box replaces hi[axis] by the split
-		recs[(size_t)R.node].saved = it.lo[n.axis];   // the right child's box replaces lo[axis]
 		L.hi[n.axis] = n.split;
 		R.lo[n.axis] = n.split;
 		todo.push_back(R);
@@ -285,10 +288,10 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		const HxrSceneDev& V = s->host_view;
 		if (counters)
 			hipLaunchKernelGGL(hxr_render_kernel<true>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures,
-			                   V.shaders, V.layers, V.lights, L);
+			                   V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, L);
 		else
 			hipLaunchKernelGGL(hxr_render_kernel<false>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures,
-			                   V.shaders, V.layers, V.lights, L);
+			                   V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, L);
 		HIP_TRY(hipGetLastError());
 	}
 	if (timed) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
@@ -337,6 +340,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		L.mode = p.mode == HXR_MODE_MONTE_CARLO ? 1 : 0;
 		L.spp = p.spp;
 		L.pixels_per_chunk = p.spp <= 64 ? 64 / p.spp : 1;
+		if (getenv("HXR_DEBUG_LANES")) L.pixels_per_chunk = atoi(getenv("HXR_DEBUG_LANES"));   // developer aid: live lanes per wave
 		L.num_chunks = (tile_pixels + (uint32_t)L.pixels_per_chunk - 1) / (uint32_t)L.pixels_per_chunk;
 		L.out = d_out;
 		L.out_stride = stride;
@@ -461,6 +465,9 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 	if (s->arena.upload(d->triangles, (size_t)d->num_triangles, &d_tris)) return fail();
 
 	std::vector<HxrMeshDev> meshes((size_t)d->num_meshes);
+	std::vector<HxrKdWide> all_kd;
+	std::vector<HxrTriHot> all_hot;
+	std::vector<int32_t> all_ids;
 	for (int64_t i = 0; i < d->num_meshes; i++) {
 		const hxr_mesh& m = d->meshes[i];
 		HxrMeshDev& o = meshes[(size_t)i];
@@ -471,19 +478,16 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		o.backface_culling = m.backface_culling;
 		o.has_kd = m.has_kd && m.num_kd_nodes > 0;
 		o.num_triangles = (int32_t)m.num_triangles;
-		std::vector<HxrKdRec> recs;
-		std::vector<HxrTriHot> hot;
-		std::vector<int32_t> ids;
-		build_kd_records(d, m, recs, hot, ids);
-		if (s->arena.upload(recs.data(), recs.size(), &o.kd)) return fail();
-		if (s->arena.upload(hot.data(), hot.size(), &o.leaf_tris)) return fail();
-		if (s->arena.upload(ids.data(), ids.size(), &o.leaf_tri_ids)) return fail();
+		append_mesh_tables(d, m, o, all_kd, all_hot, all_ids);
 		o.tris = d_tris + m.first_triangle;
 		o.vertices = d_f64 + m.first_vertex * 3;
 		o.normals = d_f64 + m.first_normal * 3;
 		o.uvs = d_f64 + m.first_uv * 3;
 	}
 	if (s->arena.upload(meshes.data(), meshes.size(), &V.meshes)) return fail();
+	if (s->arena.upload(all_kd.data(), all_kd.size(), &V.kd)) return fail();
+	if (s->arena.upload(all_hot.data(), all_hot.size(), &V.hot)) return fail();
+	if (s->arena.upload(all_ids.data(), all_ids.size(), &V.hot_ids)) return fail();
 
 	std::vector<HxrHeightfieldDev> hfs((size_t)d->num_heightfields);
 	for (int64_t i = 0; i < d->num_heightfields; i++) {

@@ -1,30 +1,32 @@
 // Device-side scene layout of the MI355X render module.
 //
 // hxr_scene_create() re-lays the flattened descriptor (include/hexray_hip.h) out for the kernels:
-//   * kd nodes become 32-byte records that carry their parent link and the box bound they override,
-//     so traversal needs NO stack: the walk goes down by tightening one bound of the box it carries in
-//     registers and comes back up by restoring it from the record (reference recursion:
-//     src/mesh.cpp:221-245, which copies a whole BBox per level);
+//   * kd nodes become 64-byte records {box, split, first child / first triangle, axis, count}: one
+//     s_load_dwordx16.  A node's box is an exact copy of root-box bounds and split positions
+//     (BBox::split only copies values, src/bbox.h:210-216), so storing it loses nothing and frees the
+//     traversal from carrying / restoring the reference's per-level BBox copies (src/mesh.cpp:233-243);
 //   * leaf triangle lists are expanded into leaf-ordered, 96-byte "hot" records (A, AB, AC, ABxAC --
 //     exactly the operands of Mesh::intersectTriangle's rejection tests, src/mesh.cpp:178-195), so a
 //     leaf is one contiguous stream instead of index -> 184-byte Triangle gathers;
+//   * the node and hot-triangle arrays of ALL meshes are concatenated and handed to the kernel as
+//     `const __restrict__` arguments: traversal control is wave-uniform, so these records are fetched with
+//     scalar loads into SGPRs, once per wave instead of once per lane;
 //   * per-hit attributes (uv / normal / dNdx / dNdy interpolation, src/mesh.cpp:196-218) are read once,
 //     for the accepted hit of the closest node only, from the "cold" tables;
 //   * small tables (nodes, shaders, layers, textures, lights) are copied verbatim: their indices are
-//     wave-uniform in the hot loops, so they are fetched through the scalar cache.
+//     wave-uniform in the hot loops, so they are fetched through the scalar cache as well.
 #pragma once
 #include <stdint.h>
 #include "hexray_hip.h"
 
 #define HXR_KD_LEAF 3
 
-struct HxrKdRec {          // 32 B, 16-B aligned: two dwordx4 loads
+struct HxrKdWide {         // 64 B, 64-B aligned: one s_load_dwordx16
+	double lo[3], hi[3];   // the node's box
 	double split;          // binary: splitPos
-	double saved;          // the parent's value of the bound THIS node's box overrides (restored on the way up)
-	int32_t first;         // binary: index of the left child (right = first + 1); leaf: first hot-triangle index
-	int32_t parent;        // -1 for the root
-	int32_t axis;          // 0..2, or HXR_KD_LEAF
-	int32_t count;         // leaf: number of triangles
+	int32_t first;         // binary: index of the left child (right = first + 1), local to the mesh;
+	                       // leaf  : index of its first hot triangle, local to the mesh
+	int32_t axis_count;    // bits 0..1: split axis, or HXR_KD_LEAF; bits 2..: number of triangles of a leaf
 };
 
 struct HxrTriHot {         // 96 B
@@ -34,9 +36,9 @@ struct HxrTriHot {         // 96 B
 struct HxrMeshDev {
 	double bbox_min[3], bbox_max[3];
 	int32_t faceted, backface_culling, has_kd, num_triangles;
-	const HxrKdRec* kd;            // node 0 = root
-	const HxrTriHot* leaf_tris;    // leaf-ordered (has_kd) or triangle-ordered (no kd) hot records
-	const int32_t* leaf_tri_ids;   // triangle number of each hot record
+	int32_t kd_first;              // this mesh's nodes in the concatenated HxrKdWide array (node 0 of the range = root)
+	int32_t hot_first;             // this mesh's leaf-ordered (has_kd) or triangle-ordered (no kd) hot records / triangle ids
+	int32_t pad_[2];
 	const hxr_triangle* tris;      // cold records of this mesh
 	const double* vertices;        // 3 doubles each (element 0 = sentinel)
 	const double* normals;
@@ -82,6 +84,9 @@ struct HxrSceneDev {
 	const hxr_layer* layers;
 	const hxr_light* lights;
 	const int32_t* env_sides;   // = &environment.side_bitmap[0] of the copy in HBM (indexed at run time; keeps this header in registers)
+	const HxrKdWide* kd;        // all meshes' kd nodes
+	const HxrTriHot* hot;       // all meshes' hot triangle records
+	const int32_t* hot_ids;     // triangle number (local to its mesh) of each hot record
 };
 
 // One frame's launch parameters (kernel argument, wave-uniform).

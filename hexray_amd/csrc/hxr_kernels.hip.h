@@ -257,16 +257,19 @@ HXR_DEV bool cube_query(const double* p, d3 o, d3 d, GeomHit& g)   // Cube::inte
 // 0 <= l1 <= 1  with gamma = a*rD, l2 = b*rD, l3 = c*rD, rD = 1/Dcr.  The conjunction does not depend on
 // the order of its terms, and  x*rD < 0  <=>  x and Dcr have opposite signs (x != 0), so the three
 // "negative" rejections are decided from signs alone BEFORE the FP64 division is paid for.
+// `first` / `count` are wave-uniform: the triangle records arrive through scalar loads.
 template <bool COUNT>
-HXR_DEV bool leaf_query(const HxrMeshDev& M, int first, int count, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g, Tally<COUNT>& tl)
+HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g,
+                        Tally<COUNT>& tl)
 {
 	bool found = false;
-	const HxrTriHot* T = M.leaf_tris + first;
+	const HxrTriHot* T = S.hot + (M.hot_first + first);
+	const int32_t* ids = S.hot_ids + (M.hot_first + first);
 	for (int i = 0; i < count; i++) {
 		tl.add(HC_TRI);
 		tl.add(HC_LEAFIDX);
 		if (M.backface_culling) {
-			const hxr_triangle& ct = M.tris[M.leaf_tri_ids[first + i]];
+			const hxr_triangle& ct = M.tris[ids[i]];
 			if (dot(d, ld3(ct.gnormal)) > 0) continue;
 		}
 		d3 N = ld3(T[i].N);
@@ -292,86 +295,115 @@ HXR_DEV bool leaf_query(const HxrMeshDev& M, int first, int count, const Box& bo
 		g.t = gamma;
 		g.l2 = l2;
 		g.l3 = l3;
-		g.tri = M.leaf_tri_ids[first + i];
+		g.tri = ids[i];
 		if (box_holds(box, o + d * gamma)) found = true;
 	}
 	return found;
 }
 
-HXR_DEV void set_lo(Box& b, int a, double v) { if (a == 0) b.lo.x = v; else if (a == 1) b.lo.y = v; else b.lo.z = v; }
-HXR_DEV void set_hi(Box& b, int a, double v) { if (a == 0) b.hi.x = v; else if (a == 1) b.hi.y = v; else b.hi.z = v; }
+// Per-wave traversal stack in LDS: (node, lanes on whose behalf it is pending).
+#define HXR_KD_STACK 200   // at most three entries per level of a depth-66 tree (checked at scene creation)
+struct WaveStack {
+	int32_t node[HXR_KD_STACK];
+	uint32_t mask_lo[HXR_KD_STACK], mask_hi[HXR_KD_STACK];
+};
 
-// Mesh::intersect (src/mesh.cpp:247-263) with a STACKLESS walk of the reference's kd-tree.
-// The reference recursion visits, at a binary node, the child on the ray origin's side first, then the
-// other, each only if the ray touches the child's box (split() of the parent's box), and stops at the
-// first leaf that reports a hit (src/mesh.cpp:233-243).  Here the current box lives in registers: going
-// down overwrites one bound with the split position, coming up restores it from the child's record
-// (HxrKdRec::saved) and uses the parent link; `tried` counts the children of the current node that are done.
-// The loop is "while-while": every lane walks inner nodes until it has a leaf to look at (or is finished);
-// only then do the lanes of the wave run their triangle loops, together.
+// Mesh::intersect (src/mesh.cpp:247-263) as a PACKET walk of the reference's kd-tree.
+//
+// The reference descends per ray: at a binary node it visits the child on the ray origin's side first,
+// then the other, each only if the ray touches that child's box, and a ray stops at the first leaf that
+// reports a hit inside the leaf's box (src/mesh.cpp:221-245).  The 64 rays of a wavefront come from one
+// 2x2..8x8 pixel block and follow almost the same path, so the WAVE walks the tree once, with wave-uniform
+// control flow, and every step carries the set of lanes on whose behalf it is taken:
+//   * a lane takes part in a node's visit iff its own reference traversal would enter that node: it took part
+//     in the parent's visit, is still searching when the node's turn comes, and its ray passes the node's box;
+//   * the visiting order is the reference's PER LANE: lanes whose origin lies on the left of the split go
+//     left-then-right, the others right-then-left.  When both groups exist the children are queued as
+//     left(for the left-first lanes), right(for everybody), left(for the right-first lanes), so each lane still
+//     sees its own near child before its own far child;
+//   * a lane that finds a hit inside its leaf's box leaves the search, exactly like the reference's `return true`.
+// Node and triangle records are the same for all lanes of a step, so they are fetched by scalar loads into
+// SGPRs; per-lane state is just the ray and its best hit.  The work counters are per lane and equal the
+// reference's per-ray counts (a box test is counted for a lane only when that lane's own traversal makes it).
 template <bool COUNT>
-HXR_DEV bool mesh_query(const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, Tally<COUNT>& tl)
+HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
 {
-	Box box{ld3(M.bbox_min), ld3(M.bbox_max)};
+	const unsigned long long me = 1ull << (threadIdx.x & 63);
+	const HxrKdWide* kd = S.kd + M.kd_first;
+	Box root{ld3(M.bbox_min), ld3(M.bbox_max)};
 	d3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
-	if (!box_test<COUNT>(box, o, d, inv, tl)) return false;
 	d3 nd = -d;
 	g.t = HXR_INF;
 	g.tri = -1;
+	bool in_root = box_test<COUNT>(root, o, d, inv, tl);
+	unsigned long long alive = __ballot(in_root);   // lanes still searching
+	if (!alive) return false;
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
-		leaf_query<COUNT>(M, 0, M.num_triangles, everything, o, d, nd, g, tl);
-		return g.t < HXR_INF;
+		if (in_root) leaf_query<COUNT>(S, M, 0, M.num_triangles, everything, o, d, nd, g, tl);
+		return in_root && g.t < HXR_INF;
 	}
-	int n = 0;
-	HxrKdRec rec = M.kd[0];
-	tl.add(HC_KD);
-	if (rec.axis == HXR_KD_LEAF) return leaf_query<COUNT>(M, rec.first, rec.count, box, o, d, nd, g, tl);
-	int tried = 0;
-	bool walking = true;
+	bool found = false;
+	int sp = 0;
+	int node = 0;
+	unsigned long long mask = alive;   // lanes taking part in the visit of `node`
+	if (in_root) tl.add(HC_KD);
 	for (;;) {
-		int leaf_first = -1, leaf_count = 0, a = 0, c = 0;
-		double old = 0;
-		while (walking && leaf_first < 0) {
-			if (tried == 2) {   // both children done: return to the parent
-				if (rec.parent < 0) { walking = false; break; }
-				int p = rec.parent;
-				HxrKdRec prec = M.kd[p];
-				bool was_left = (n == prec.first);
-				if (was_left) set_hi(box, prec.axis, rec.saved); else set_lo(box, prec.axis, rec.saved);
-				int first = comp(o, prec.axis) > prec.split ? 1 : 0;
-				tried = ((was_left ? 0 : 1) == first) ? 1 : 2;
-				n = p;
-				rec = prec;
-				continue;
+		const HxrKdWide& R = kd[node];
+		const int ac = R.axis_count;
+		const int axis = ac & 3;
+		if (axis == HXR_KD_LEAF) {
+			bool here = false;
+			if (mask & me) {
+				Box box{ld3(R.lo), ld3(R.hi)};
+				here = leaf_query<COUNT>(S, M, R.first, ac >> 2, box, o, d, nd, g, tl);
+				found = found || here;
 			}
-			a = rec.axis;
-			int first = comp(o, a) > rec.split ? 1 : 0;
-			c = tried == 0 ? first : 1 - first;
-			int child = rec.first + c;
-			HxrKdRec crec = M.kd[child];   // issued before the box test so that its latency overlaps it
-			old = c == 0 ? comp(box.hi, a) : comp(box.lo, a);
-			if (c == 0) set_hi(box, a, rec.split); else set_lo(box, a, rec.split);
-			if (box_test<COUNT>(box, o, d, inv, tl)) {
-				tl.add(HC_KD);
-				if (crec.axis == HXR_KD_LEAF) {
-					leaf_first = crec.first;
-					leaf_count = crec.count;
-				} else {
-					n = child;
-					rec = crec;
-					tried = 0;
-				}
+			alive &= ~__ballot(here);
+		} else {
+			const double split = R.split;
+			const int left = R.first;
+			bool right_first = (mask & me) && comp(o, axis) > split;
+			unsigned long long rm = __ballot(right_first), lm = mask & ~rm;
+			// queue the visits in reverse order of execution
+			if (lm && rm) {
+				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
+				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)mask; st.mask_hi[sp] = (uint32_t)(mask >> 32); sp++;
+				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
+			} else if (lm) {
+				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
+				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
 			} else {
-				if (c == 0) set_hi(box, a, old); else set_lo(box, a, old);
-				tried++;
+				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
+				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
 			}
 		}
-		if (leaf_first < 0) return false;
-		if (leaf_query<COUNT>(M, leaf_first, leaf_count, box, o, d, nd, g, tl)) return true;
-		if (c == 0) set_hi(box, a, old); else set_lo(box, a, old);
-		tried++;
+		// next pending visit whose lanes are still searching and whose box at least one of them reaches
+		bool descended = false;
+		while (sp > 0) {
+			sp--;
+			int cn = __builtin_amdgcn_readfirstlane(st.node[sp]);
+			unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.mask_lo[sp]);
+			unsigned long long m = pm & alive;
+			if (!m) continue;
+			const HxrKdWide& C = kd[cn];
+			bool pass = false;
+			if (m & me) {
+				Box cb{ld3(C.lo), ld3(C.hi)};
+				pass = box_test<COUNT>(cb, o, d, inv, tl);
+				if (pass) tl.add(HC_KD);
+			}
+			unsigned long long m2 = __ballot(pass);
+			if (m2) {
+				node = cn;
+				mask = m2;
+				descended = true;
+				break;
+			}
+		}
+		if (!descended) break;
 	}
+	return found;
 }
 
 // intersectTriangleFast, src/mesh.cpp:131-170
@@ -462,13 +494,13 @@ HXR_DEV d3 heightfield_normal(const HxrHeightfieldDev& F, float x, float y)
 // nodes
 // ------------------------------------------------------------------------------------------------
 template <bool COUNT>
-HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, GeomHit& g, Tally<COUNT>& tl)
+HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
 {
 	switch (N.geom_type) {
 		case HXR_GEOM_PLANE: return plane_query(N.p, ol, dl, g);
 		case HXR_GEOM_SPHERE: return sphere_query(N.p, ol, dl, g);
 		case HXR_GEOM_CUBE: return cube_query(N.p, ol, dl, g);
-		case HXR_GEOM_MESH: return mesh_query<COUNT>(S.meshes[N.ref], ol, dl, g, tl);
+		case HXR_GEOM_MESH: return mesh_query<COUNT>(S, S.meshes[N.ref], ol, dl, g, st, tl);
 		case HXR_GEOM_HEIGHTFIELD: return heightfield_query<COUNT>(S.heightfields[N.ref], ol, dl, g, tl);
 		default: return false;   // CSG is rejected at scene creation (HXR_E_UNSUPPORTED)
 	}
@@ -476,13 +508,13 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 
 // Node::intersect (src/geometry.cpp:196-208) up to the world-space distance
 template <bool COUNT>
-HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, Tally<COUNT>& tl)
+HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, WaveStack& st, Tally<COUNT>& tl)
 {
 	const HxrNodeDev& N = S.nodes[__builtin_amdgcn_readfirstlane(ni)];   // the node scan is wave-uniform: scalar loads
 	tl.add(HC_NODE);
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
-	if (!geometry_query<COUNT>(S, N, ol, dl, g, tl)) return false;
+	if (!geometry_query<COUNT>(S, N, ol, dl, g, st, tl)) return false;
 	d3 ipw = mulm(ol + dl * g.t, N.T.m) + ld3(N.T.offset);
 	wdist = dist3(o, ipw);
 	return true;
@@ -732,14 +764,14 @@ HXR_DEV f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
 // hit closer than |AB|).  Both compare `info.dist < limit`; raycast lowers the limit as it goes,
 // visible() leaves the scan at the first success.  Returns the node index or -1.
 template <bool COUNT>
-HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any, GeomHit& bg, double& bw, Tally<COUNT>& tl)
+HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any, GeomHit& bg, double& bw, WaveStack& st, Tally<COUNT>& tl)
 {
 	int node = -1;
 	bw = limit;
 	for (int ni = 0; ni < S.num_nodes; ni++) {
 		GeomHit g;
 		double w;
-		if (node_query<COUNT>(S, ni, o, d, g, w, tl) && w < bw) {
+		if (node_query<COUNT>(S, ni, o, d, g, w, st, tl) && w < bw) {
 			bw = w;
 			bg = g;
 			node = ni;
@@ -799,7 +831,7 @@ struct HitPoint {
 enum { Q_NONE = 0, Q_CLOSEST = 1, Q_SHADOW = 2 };
 
 template <bool COUNT>
-HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Tally<COUNT>& tl)
+HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
 {
 	const bool gi = S.settings.gi != 0;
 	RayItem stack[HXR_RAY_STACK];
@@ -846,7 +878,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Tall
 		// ---- 2. the one traversal site
 		GeomHit bg;
 		double bw;
-		int node = scene_query<COUNT>(S, qo, qd, qlimit, qany, bg, bw, tl);
+		int node = scene_query<COUNT>(S, qo, qd, qlimit, qany, bg, bw, st, tl);
 
 		// ---- 3. consume the answer
 		bool shade_next = false;   // run the shader work list
@@ -1105,7 +1137,7 @@ HXR_DEV void camera_ray(const HxrSceneDev& S, int W, int H, double x, double y, 
 }
 
 template <bool COUNT>
-HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, const RngCtx& rc, Tally<COUNT>& tl)
+HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
 {
 	double lu = 0, lv = 0;
 	tl.add(HC_SAMPLES);
@@ -1120,12 +1152,12 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	d3 o, d;
 	if (S.camera.stereo_separation == 0.0) {
 		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
-		return trace_rays<COUNT>(S, o, d, rc, tl);
+		return trace_rays<COUNT>(S, o, d, rc, st, tl);
 	}
 	f3 eye[2];
 	for (int e = 0; e < 2; e++) {   // anaglyph pair (src/main.cpp:237-247)
 		camera_ray(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
-		eye[e] = trace_rays<COUNT>(S, o, d, rc, tl);
+		eye[e] = trace_rays<COUNT>(S, o, d, rc, st, tl);
 	}
 	float ml = intensity(eye[0]), mr = intensity(eye[1]);
 	return mkf(ml + (eye[0].x - ml) * 0.3f, mr + (eye[1].y - mr) * 0.3f, mr + (eye[1].z - mr) * 0.3f);
@@ -1182,7 +1214,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
     const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
-    const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights, HxrLaunch P)
+    const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights,
+    const HxrKdWide* __restrict__ a_kd, const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids, HxrLaunch P)
 {
 	// The small tables arrive as separate `const __restrict__` kernel arguments: only then can the compiler
 	// prove that the frame / counter stores of this kernel never clobber them, and fetch their wave-uniform
@@ -1196,7 +1229,11 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 	S.shaders = a_shaders;
 	S.layers = a_layers;
 	S.lights = a_lights;
+	S.kd = a_kd;
+	S.hot = a_hot;
+	S.hot_ids = a_hot_ids;
 	__shared__ float lds_rgb[HXR_BLOCK / 64][64][3];
+	__shared__ WaveStack lds_stack[HXR_BLOCK / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	Tally<COUNT> tl;
 	tl.clear();
@@ -1250,7 +1287,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 					sx = (double)((float)x + kx[s]);
 					sy = (double)((float)y + ky[s]);
 				}
-				f3 c = trace_sample<COUNT>(S, P.W, P.H, sx, sy, rc, tl);
+				f3 c = trace_sample<COUNT>(S, P.W, P.H, sx, sy, rc, lds_stack[wave], tl);
 				sum = (rd == 0) ? c : sum + c;
 			}
 		}
