@@ -72,12 +72,13 @@ struct hxr_scene {
 	HxrSceneDev* dev = nullptr;     // the same struct in HBM
 	hxr_settings settings;
 	hxr_camera camera;
+	unsigned features = 0;          // HXR_F_* geometry kinds present among the nodes
 	// per-frame scratch, grown on demand
 	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
 	float* d_scratch = nullptr;     size_t scratch_bytes = 0;  // sharded-AA full frame
 	int32_t* d_aa_list = nullptr;   size_t aa_capacity = 0;
 	int32_t* d_extra = nullptr;     size_t extra_capacity = 0;
-	uint32_t* d_work = nullptr;     // [0] dispenser pass 1/MC, [1] dispenser pass 3, [2] aa count
+	uint32_t* d_work = nullptr;     // [0..255] dispenser shards pass 1 / MC, [256..511] dispenser shards pass 3, [512] aa count
 	unsigned long long* d_counters = nullptr;
 	uint8_t* d_lut = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -269,7 +270,7 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 	L.seed = p.seed;
 	L.tile_size = p.tile; L.tiles_x = p.tiles_x; L.tiles_y = p.tiles_y;
 	L.shard_rank = p.rank; L.shard_count = p.count; L.num_shard_tiles = p.ntiles;
-	L.aa_count = (const int32_t*)(s->d_work + 2);
+	L.aa_count = (const int32_t*)(s->d_work + 512);
 }
 
 int grid_for(uint32_t chunks)
@@ -286,12 +287,23 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 	if (L.num_chunks > 0) {
 		int grid = grid_for(L.num_chunks);
 		const HxrSceneDev& V = s->host_view;
-		if (counters)
-			hipLaunchKernelGGL(hxr_render_kernel<true>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures,
-			                   V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, L);
-		else
-			hipLaunchKernelGGL(hxr_render_kernel<false>, dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures,
-			                   V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, L);
+#define HXR_LAUNCH(CNT, FEAT)                                                                                                                   \
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, \
+	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, L)
+#define HXR_LAUNCH_F(FEAT)                                                  \
+	do {                                                                    \
+		if (counters) HXR_LAUNCH(true, FEAT); else HXR_LAUNCH(false, FEAT); \
+	} while (0)
+		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h)
+		const unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE);
+		const bool gi = s->settings.gi != 0;
+		if (!gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH);
+		else if (!gi && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD);
+		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI);
+		else if (gi) HXR_LAUNCH_F(HXR_F_ALL);
+		else HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI);
+#undef HXR_LAUNCH_F
+#undef HXR_LAUNCH
 		HIP_TRY(hipGetLastError());
 	}
 	if (timed) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
@@ -327,7 +339,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (p.layout == HXR_LAYOUT_FRAME && stride < (size_t)p.W * 12) { set_err("row stride smaller than a row"); return HXR_E_INVALID; }
 	const bool counters = fp->collect_counters != 0;
-	HIP_TRY(hipMemsetAsync(s->d_work, 0, 4 * sizeof(uint32_t), st));
+	HIP_TRY(hipMemsetAsync(s->d_work, 0, 1024 * sizeof(uint32_t), st));
 	if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
 	s->counters_valid = counters;
 	s->timed = false;
@@ -389,7 +401,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (tile_pixels) {
 		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)g_num_cu * 8u);
-		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 2));
+		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512));
 		HIP_TRY(hipGetLastError());
 	}
 	// pass 3: the flagged-pixel count stays on the device; launch enough waves for the worst case and let them drain
@@ -400,7 +412,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	L3.num_extra_pixels = 0;
 	L3.aa_list = s->d_aa_list;
 	L3.num_chunks = (tile_pixels + 15u) / 16u;
-	L3.work_counter = s->d_work + 1;
+	L3.work_counter = s->d_work + 256;
 	rc = launch_render(s, L3, counters, st, false);
 	if (rc) return rc;
 	if (!direct) {
@@ -519,6 +531,10 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		HxrNodeDev& o = nodes[(size_t)i];
 		memset(&o, 0, sizeof o);
 		o.T = n.T;
+		if (g.type == HXR_GEOM_MESH) s->features |= HXR_F_MESH;
+		else if (g.type == HXR_GEOM_HEIGHTFIELD) s->features |= HXR_F_HEIGHTFIELD;
+		else if (g.type == HXR_GEOM_SPHERE) s->features |= HXR_F_SPHERE;
+		else if (g.type == HXR_GEOM_CUBE) s->features |= HXR_F_CUBE;
 		o.geom_type = g.type;
 		o.geom = n.geometry;
 		o.ref = g.ref;
@@ -540,7 +556,7 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 	if (s->arena.upload(&V, 1, &dv)) return fail();
 	s->dev = const_cast<HxrSceneDev*>(dv);
 	void* p = nullptr;
-	if (s->arena.alloc(4 * sizeof(uint32_t), &p)) return fail();
+	if (s->arena.alloc(1024 * sizeof(uint32_t), &p)) return fail();
 	s->d_work = (uint32_t*)p;
 	if (s->arena.alloc(sizeof(hxr_counters), &p)) return fail();
 	s->d_counters = (unsigned long long*)p;
@@ -687,9 +703,9 @@ int hxr_get_counters(const hxr_scene* s, hxr_counters* out)
 	HIP_TRY(hipMemcpy(raw, s->d_counters, sizeof raw, hipMemcpyDeviceToHost));
 	uint64_t* o = (uint64_t*)out;
 	for (int i = 0; i < HC_NUM; i++) o[i] = raw[i];
-	uint32_t work[4];
-	HIP_TRY(hipMemcpy(work, s->d_work, sizeof work, hipMemcpyDeviceToHost));
-	out->aa_pixels = work[2];
+	uint32_t flagged = 0;
+	HIP_TRY(hipMemcpy(&flagged, s->d_work + 512, sizeof flagged, hipMemcpyDeviceToHost));
+	out->aa_pixels = flagged;
 	return 0;
 }
 

@@ -25,6 +25,20 @@
 #define HXR_RAY_STACK 12              // pending secondary rays per lane (checked against the scene at create time)
 #define HXR_SHADER_STACK 8            // pending (shader, weight) pairs while a hit is being shaded
 #define HXR_DEV __device__ __forceinline__
+#ifdef HXR_NOINLINE_HELPERS
+#define HXR_DEVX __device__ __noinline__
+#else
+#define HXR_DEVX __device__ __forceinline__
+#endif
+
+// Kernel specialisation.  The register allocation of a kernel is set by its hungriest code path, whether or not
+// a scene ever runs it (the heightfield marcher alone wants 96 VGPRs, the packet kd walk 60), so the render
+// kernel is compiled for the feature sets scenes actually have and the launcher picks the smallest fit.
+enum : unsigned {
+	HXR_F_MESH = 1u, HXR_F_HEIGHTFIELD = 2u, HXR_F_SPHERE = 4u, HXR_F_CUBE = 8u,   // geometry kinds besides Plane
+	HXR_F_GI = 16u,                                                                 // pathtrace() instead of raytrace()
+	HXR_F_ALL = 31u
+};
 
 // counters (COUNT builds only); order = hxr_counters
 enum {
@@ -141,7 +155,9 @@ HXR_DEV bool box_hit(const Box& b, d3 o, d3 d, d3 inv)
 	double tz0 = (b.lo.z - o.z) * inv.z, tz1 = (b.hi.z - o.z) * inv.z;
 	double tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmin(tz0, tz1));
 	double tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmax(tz0, tz1));
-	return (tn <= tf && tf >= 0) || box_holds(b, o);
+	bool r = tn <= tf && tf >= 0;
+	if (__ballot(!r)) r = r || box_holds(b, o);   // the inflated inside() shortcut only matters for lanes the slabs reject
+	return r;
 }
 
 template <bool COUNT>
@@ -251,62 +267,65 @@ HXR_DEV bool cube_query(const double* p, d3 o, d3 d, GeomHit& g)   // Cube::inte
 	return face >= 0;
 }
 
+// Per-wave traversal stack in LDS: (node, lanes on whose behalf it is pending).
+#define HXR_KD_STACK 200     // at most three entries per level of a depth-66 tree
+struct WaveStack {
+	int32_t node[HXR_KD_STACK];
+	uint32_t mask_lo[HXR_KD_STACK], mask_hi[HXR_KD_STACK];
+};
+
 // Leaf of Mesh::intersectKD (src/mesh.cpp:223-232): every triangle is tested against the running
 // best distance; a hit counts for THIS leaf only if its point lies in the leaf's box.
 // Mesh::intersectTriangle (src/mesh.cpp:178-195) accepts iff  0 <= gamma <= best, 0 <= l2 <= 1, 0 <= l3 <= 1,
 // 0 <= l1 <= 1  with gamma = a*rD, l2 = b*rD, l3 = c*rD, rD = 1/Dcr.  The conjunction does not depend on
 // the order of its terms, and  x*rD < 0  <=>  x and Dcr have opposite signs (x != 0), so the three
 // "negative" rejections are decided from signs alone BEFORE the FP64 division is paid for.
-// `first` / `count` are wave-uniform: the triangle records arrive through scalar loads.
+// `first` / `count` are wave-uniform: the hot records (contiguous, leaf order) arrive through scalar loads
+// and stay in SGPRs, so a triangle costs the lanes no vector registers.
 template <bool COUNT>
-HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g,
-                        Tally<COUNT>& tl)
+HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, bool mine, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g,
+                        WaveStack& st, Tally<COUNT>& tl)
 {
 	bool found = false;
 	const HxrTriHot* T = S.hot + (M.hot_first + first);
 	const int32_t* ids = S.hot_ids + (M.hot_first + first);
-	for (int i = 0; i < count; i++) {
-		tl.add(HC_TRI);
-		tl.add(HC_LEAFIDX);
-		if (M.backface_culling) {
-			const hxr_triangle& ct = M.tris[ids[i]];
-			if (dot(d, ld3(ct.gnormal)) > 0) continue;
+	if (mine) {
+		for (int i = 0; i < count; i++) {
+			tl.add(HC_TRI);
+			tl.add(HC_LEAFIDX);
+			if (M.backface_culling) {
+				const hxr_triangle& ct = M.tris[ids[i]];
+				if (dot(d, ld3(ct.gnormal)) > 0) continue;
+			}
+			d3 N = ld3(T[i].N);
+			double Dcr = dot(N, nd);
+			if (fabs(Dcr) < 1e-12) continue;
+			d3 H = o - ld3(T[i].A);
+			bool neg = Dcr < 0;
+			double ga = dot(N, H);
+			if ((ga < 0) != neg && ga != 0) continue;          // gamma < 0
+			double gb = dot(cross(H, ld3(T[i].AC)), nd);
+			if ((gb < 0) != neg && gb != 0) continue;          // lambda2 < 0
+			double gc = dot(cross(ld3(T[i].AB), H), nd);
+			if ((gc < 0) != neg && gc != 0) continue;          // lambda3 < 0
+			double rD = 1 / Dcr;
+			double gamma = ga * rD;
+			if (gamma < 0 || gamma > g.t) continue;
+			double l2 = gb * rD;
+			if (l2 < 0 || l2 > 1) continue;
+			double l3 = gc * rD;
+			if (l3 < 0 || l3 > 1) continue;
+			double l1 = 1 - (l2 + l3);
+			if (l1 < 0 || l1 > 1) continue;
+			g.t = gamma;
+			g.l2 = l2;
+			g.l3 = l3;
+			g.tri = ids[i];
+			if (box_holds(box, o + d * gamma)) found = true;
 		}
-		d3 N = ld3(T[i].N);
-		double Dcr = dot(N, nd);
-		if (fabs(Dcr) < 1e-12) continue;
-		d3 H = o - ld3(T[i].A);
-		bool neg = Dcr < 0;
-		double ga = dot(N, H);
-		if ((ga < 0) != neg && ga != 0) continue;          // gamma < 0
-		double gb = dot(cross(H, ld3(T[i].AC)), nd);
-		if ((gb < 0) != neg && gb != 0) continue;          // lambda2 < 0
-		double gc = dot(cross(ld3(T[i].AB), H), nd);
-		if ((gc < 0) != neg && gc != 0) continue;          // lambda3 < 0
-		double rD = 1 / Dcr;
-		double gamma = ga * rD;
-		if (gamma < 0 || gamma > g.t) continue;
-		double l2 = gb * rD;
-		if (l2 < 0 || l2 > 1) continue;
-		double l3 = gc * rD;
-		if (l3 < 0 || l3 > 1) continue;
-		double l1 = 1 - (l2 + l3);
-		if (l1 < 0 || l1 > 1) continue;
-		g.t = gamma;
-		g.l2 = l2;
-		g.l3 = l3;
-		g.tri = ids[i];
-		if (box_holds(box, o + d * gamma)) found = true;
 	}
 	return found;
 }
-
-// Per-wave traversal stack in LDS: (node, lanes on whose behalf it is pending).
-#define HXR_KD_STACK 200   // at most three entries per level of a depth-66 tree (checked at scene creation)
-struct WaveStack {
-	int32_t node[HXR_KD_STACK];
-	uint32_t mask_lo[HXR_KD_STACK], mask_hi[HXR_KD_STACK];
-};
 
 // Mesh::intersect (src/mesh.cpp:247-263) as a PACKET walk of the reference's kd-tree.
 //
@@ -322,9 +341,11 @@ struct WaveStack {
 //     left(for the left-first lanes), right(for everybody), left(for the right-first lanes), so each lane still
 //     sees its own near child before its own far child;
 //   * a lane that finds a hit inside its leaf's box leaves the search, exactly like the reference's `return true`.
-// Node and triangle records are the same for all lanes of a step, so they are fetched by scalar loads into
-// SGPRs; per-lane state is just the ray and its best hit.  The work counters are per lane and equal the
-// reference's per-ray counts (a box test is counted for a lane only when that lane's own traversal makes it).
+// Node records are the same for all lanes of a step, so they are fetched by scalar loads into SGPRs -- both
+// children of a binary node at once (they are adjacent, 128 B), as soon as the node is entered, because the
+// next box test is always against one of them; per-lane state is just the ray and its best hit.  The work
+// counters are per lane and equal the reference's per-ray counts (a box test is counted for a lane only when
+// that lane's own traversal makes it).
 template <bool COUNT>
 HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
 {
@@ -340,53 +361,71 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	if (!alive) return false;
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
-		if (in_root) leaf_query<COUNT>(S, M, 0, M.num_triangles, everything, o, d, nd, g, tl);
+		leaf_query<COUNT>(S, M, 0, M.num_triangles, in_root, everything, o, d, nd, g, st, tl);
 		return in_root && g.t < HXR_INF;
 	}
 	bool found = false;
 	int sp = 0;
-	int node = 0;
-	unsigned long long mask = alive;   // lanes taking part in the visit of `node`
+	unsigned long long mask = alive;   // lanes taking part in the visit of the current node
 	if (in_root) tl.add(HC_KD);
+	HxrKdWide R = kd[0];               // record of the current node (scalar registers)
 	for (;;) {
-		const HxrKdWide& R = kd[node];
 		const int ac = R.axis_count;
 		const int axis = ac & 3;
+		// `next` / `next_mask`: a visit to try right away (its box is derived from R, no load needed); otherwise pop
+		int next = -1;
+		unsigned long long next_mask = 0;
+		Box nb{ld3(R.lo), ld3(R.hi)};
+		HxrKdWide kid0, kid1;
 		if (axis == HXR_KD_LEAF) {
-			bool here = false;
-			if (mask & me) {
-				Box box{ld3(R.lo), ld3(R.hi)};
-				here = leaf_query<COUNT>(S, M, R.first, ac >> 2, box, o, d, nd, g, tl);
-				found = found || here;
-			}
+			bool here = leaf_query<COUNT>(S, M, R.first, ac >> 2, (mask & me) != 0, nb, o, d, nd, g, st, tl);
+			found = found || here;
 			alive &= ~__ballot(here);
 		} else {
 			const double split = R.split;
 			const int left = R.first;
+			kid0 = kd[left];           // in flight while the first child's box is being tested
+			kid1 = kd[left + 1];
 			bool right_first = (mask & me) && comp(o, axis) > split;
 			unsigned long long rm = __ballot(right_first), lm = mask & ~rm;
-			// queue the visits in reverse order of execution
+			// the visits of this node's children, in execution order: first one directly, the others through the stack
 			if (lm && rm) {
 				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
 				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)mask; st.mask_hi[sp] = (uint32_t)(mask >> 32); sp++;
-				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
+				next = left; next_mask = lm;
 			} else if (lm) {
 				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
-				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
+				next = left; next_mask = lm;
 			} else {
 				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
-				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
+				next = left + 1; next_mask = rm;
+			}
+			// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
+			if (next == left) { if (axis == 0) nb.hi.x = split; else if (axis == 1) nb.hi.y = split; else nb.hi.z = split; }
+			else { if (axis == 0) nb.lo.x = split; else if (axis == 1) nb.lo.y = split; else nb.lo.z = split; }
+		}
+		bool descended = false;
+		if (next >= 0) {   // first child of the node just entered: nobody has found anything since `mask` was formed
+			bool pass = false;
+			if (next_mask & me) {
+				pass = box_test<COUNT>(nb, o, d, inv, tl);
+				if (pass) tl.add(HC_KD);
+			}
+			unsigned long long m2 = __ballot(pass);
+			if (m2) {
+				R = (next == R.first) ? kid0 : kid1;
+				mask = m2;
+				descended = true;
 			}
 		}
-		// next pending visit whose lanes are still searching and whose box at least one of them reaches
-		bool descended = false;
-		while (sp > 0) {
+		// otherwise the next pending visit whose lanes are still searching and whose box at least one of them reaches
+		while (!descended && sp > 0) {
 			sp--;
 			int cn = __builtin_amdgcn_readfirstlane(st.node[sp]);
 			unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.mask_lo[sp]);
 			unsigned long long m = pm & alive;
 			if (!m) continue;
-			const HxrKdWide& C = kd[cn];
+			HxrKdWide C = kd[cn];
 			bool pass = false;
 			if (m & me) {
 				Box cb{ld3(C.lo), ld3(C.hi)};
@@ -395,10 +434,9 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			}
 			unsigned long long m2 = __ballot(pass);
 			if (m2) {
-				node = cn;
+				R = C;
 				mask = m2;
 				descended = true;
-				break;
 			}
 		}
 		if (!descended) break;
@@ -493,28 +531,36 @@ HXR_DEV d3 heightfield_normal(const HxrHeightfieldDev& F, float x, float y)
 // ------------------------------------------------------------------------------------------------
 // nodes
 // ------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
 {
 	switch (N.geom_type) {
 		case HXR_GEOM_PLANE: return plane_query(N.p, ol, dl, g);
-		case HXR_GEOM_SPHERE: return sphere_query(N.p, ol, dl, g);
-		case HXR_GEOM_CUBE: return cube_query(N.p, ol, dl, g);
-		case HXR_GEOM_MESH: return mesh_query<COUNT>(S, S.meshes[N.ref], ol, dl, g, st, tl);
-		case HXR_GEOM_HEIGHTFIELD: return heightfield_query<COUNT>(S.heightfields[N.ref], ol, dl, g, tl);
+		case HXR_GEOM_SPHERE:
+			if constexpr ((F & HXR_F_SPHERE) != 0) return sphere_query(N.p, ol, dl, g);
+			return false;
+		case HXR_GEOM_CUBE:
+			if constexpr ((F & HXR_F_CUBE) != 0) return cube_query(N.p, ol, dl, g);
+			return false;
+		case HXR_GEOM_MESH:
+			if constexpr ((F & HXR_F_MESH) != 0) return mesh_query<COUNT>(S, S.meshes[N.ref], ol, dl, g, st, tl);
+			return false;
+		case HXR_GEOM_HEIGHTFIELD:
+			if constexpr ((F & HXR_F_HEIGHTFIELD) != 0) return heightfield_query<COUNT>(S.heightfields[N.ref], ol, dl, g, tl);
+			return false;
 		default: return false;   // CSG is rejected at scene creation (HXR_E_UNSUPPORTED)
 	}
 }
 
 // Node::intersect (src/geometry.cpp:196-208) up to the world-space distance
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, WaveStack& st, Tally<COUNT>& tl)
 {
 	const HxrNodeDev& N = S.nodes[__builtin_amdgcn_readfirstlane(ni)];   // the node scan is wave-uniform: scalar loads
 	tl.add(HC_NODE);
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
-	if (!geometry_query<COUNT>(S, N, ol, dl, g, st, tl)) return false;
+	if (!geometry_query<COUNT, F>(S, N, ol, dl, g, st, tl)) return false;
 	d3 ipw = mulm(ol + dl * g.t, N.T.m) + ld3(N.T.offset);
 	wdist = dist3(o, ipw);
 	return true;
@@ -527,8 +573,8 @@ struct Surface {
 	double u, v;
 };
 
-template <bool COUNT>
-HXR_DEV void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit& g, double wdist, Surface& sf, Tally<COUNT>& tl)
+template <bool COUNT, unsigned F>
+HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit& g, double wdist, Surface& sf, Tally<COUNT>& tl)
 {
 	const HxrNodeDev& N = S.nodes[ni];
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
@@ -546,7 +592,7 @@ HXR_DEV void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit&
 			sf.dNdx = mk3(1, 0, 0);
 			sf.dNdy = mk3(0, 0, 1);
 			break;
-		case HXR_GEOM_SPHERE: {
+		case HXR_GEOM_SPHERE: if constexpr ((F & HXR_F_SPHERE) != 0) {
 			n = unit(ip - ld3(N.p));
 			double v = asin(n.y), u = atan2(n.z, n.x);
 			v = -(v / HXR_PI + 0.5f);
@@ -556,7 +602,7 @@ HXR_DEV void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit&
 			sf.v = v;
 			break;
 		}
-		case HXR_GEOM_CUBE: {
+		case HXR_GEOM_CUBE: if constexpr ((F & HXR_F_CUBE) != 0) {
 			int a = g.tri >> 1;
 			double sg = (g.tri & 1) ? 1 : -1;
 			n = mk3(a == 0 ? sg : 0, a == 1 ? sg : 0, a == 2 ? sg : 0);
@@ -565,7 +611,7 @@ HXR_DEV void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit&
 			else { sf.u = ip.x; sf.v = ip.y; }
 			break;
 		}
-		case HXR_GEOM_MESH: {   // Mesh::intersectTriangle's attribute half, src/mesh.cpp:196-218
+		case HXR_GEOM_MESH: if constexpr ((F & HXR_F_MESH) != 0) {   // Mesh::intersectTriangle's attribute half, src/mesh.cpp:196-218
 			const HxrMeshDev& M = S.meshes[N.ref];
 			const hxr_triangle& t = M.tris[g.tri];
 			tl.add(HC_MESHHIT);
@@ -583,12 +629,12 @@ HXR_DEV void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit&
 			sf.dNdy = ld3(t.dNdy);
 			break;
 		}
-		case HXR_GEOM_HEIGHTFIELD: {
-			const HxrHeightfieldDev& F = S.heightfields[N.ref];
+		case HXR_GEOM_HEIGHTFIELD: if constexpr ((F & HXR_F_HEIGHTFIELD) != 0) {
+			const HxrHeightfieldDev& Hf = S.heightfields[N.ref];
 			tl.add(HC_HFNORM);
-			n = heightfield_normal(F, (float)ip.x, (float)ip.z);
-			sf.u = ip.x / F.W;
-			sf.v = ip.z / F.H;
+			n = heightfield_normal(Hf, (float)ip.x, (float)ip.z);
+			sf.u = ip.x / Hf.W;
+			sf.v = ip.z / Hf.H;
 			sf.dNdx = mk3(1, 0, 0);
 			sf.dNdy = mk3(0, 0, 1);
 			break;
@@ -670,7 +716,7 @@ HXR_DEV f3 bitmap_bilinear(const HxrBitmapDev& b, float x, float y)   // Bitmap:
 }
 
 template <bool COUNT>
-HXR_DEV f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& sf, Tally<COUNT>& tl)
+HXR_DEVX f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& sf, Tally<COUNT>& tl)
 {
 	const hxr_texture& t = S.textures[ti];
 	switch (t.type) {
@@ -703,7 +749,7 @@ HXR_DEV f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& s
 }
 
 template <bool COUNT>
-HXR_DEV void texture_bump(const HxrSceneDev& S, int ti, Surface& sf, Tally<COUNT>& tl)
+HXR_DEVX void texture_bump(const HxrSceneDev& S, int ti, Surface& sf, Tally<COUNT>& tl)
 {
 	const hxr_texture& t = S.textures[ti];
 	if (t.type == HXR_TEX_BUMPTEX) {   // BumpTexture::modifyNormal, src/shading.cpp:345-356
@@ -732,7 +778,7 @@ HXR_DEV void texture_bump(const HxrSceneDev& S, int ti, Surface& sf, Tally<COUNT
 
 // CubemapEnvironment::getEnvironment, src/environment.cpp:54-81
 template <bool COUNT>
-HXR_DEV f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
+HXR_DEVX f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
 {
 	if (!S.environment.loaded) return mkf(0, 0, 0);
 	int dim = 0;
@@ -763,15 +809,19 @@ HXR_DEV f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
 // world-space hit distance is smallest) and visible() (src/main.cpp:179-184: stop at the first node
 // hit closer than |AB|).  Both compare `info.dist < limit`; raycast lowers the limit as it goes,
 // visible() leaves the scan at the first success.  Returns the node index or -1.
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any, GeomHit& bg, double& bw, WaveStack& st, Tally<COUNT>& tl)
 {
 	int node = -1;
 	bw = limit;
+#ifdef HXR_STUB_QUERY   // developer aid: measure the integrator's own register footprint
+	if (o.x * d.y > limit) { bw = o.z; bg.t = d.x; bg.l2 = d.y; bg.l3 = d.z; bg.tri = (int)o.y; return 0; }
+	return -1;
+#endif
 	for (int ni = 0; ni < S.num_nodes; ni++) {
 		GeomHit g;
 		double w;
-		if (node_query<COUNT>(S, ni, o, d, g, w, st, tl) && w < bw) {
+		if (node_query<COUNT, F>(S, ni, o, d, g, w, st, tl) && w < bw) {
 			bw = w;
 			bg = g;
 			node = ni;
@@ -828,12 +878,22 @@ struct HitPoint {
 // Between two queries a lane finishes whatever needs no ray: light hits, environment, textures, the
 // Layered expansion (src/shading.cpp:315-324), pushing Reflection / Refraction rays (:159-232) with their
 // weights, BRDF spawn / eval for path tracing (:93-109,189-263).
+//
+// Table records (node, shader, light, texture) are selected by per-lane indices here.  Reading them with
+// those indices would pull whole records -- a 240-byte Transform per node or light -- into vector registers
+// of every lane.  Instead each distinct index present in the wave is handled in turn ("waterfall":
+// readfirstlane picks an index, the lanes that hold it run the body with a wave-uniform index, the record
+// arrives through scalar loads); a wave holds one to three distinct values in practice.
 enum { Q_NONE = 0, Q_CLOSEST = 1, Q_SHADOW = 2 };
 
-template <bool COUNT>
+#define HXR_WATERFALL(var, uni)                                                        \
+	for (bool wf_done_ = false; !wf_done_;)                                            \
+		for (const int uni = __builtin_amdgcn_readfirstlane(var); !wf_done_ && (var) == uni; wf_done_ = true)
+
+template <bool COUNT, unsigned F>
 HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
 {
-	const bool gi = S.settings.gi != 0;
+	constexpr bool gi = (F & HXR_F_GI) != 0;   // the launcher picks the variant that matches settings.gi
 	RayItem stack[HXR_RAY_STACK];
 	int sh_stack[HXR_SHADER_STACK];
 	f3 w_stack[HXR_SHADER_STACK];
@@ -850,82 +910,78 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 	int li = 0, ls = 0;           // light / sample cursor
 	bool in_lights = false;
 
-	for (;;) {
+	while (want != Q_NONE) {
 		// ---- 1. what does this lane ask the scene?
 		d3 qo = cur.o, qd = cur.d;
 		double qlimit = HXR_INF;
 		bool qany = false;
 		if (want == Q_CLOSEST) {
-			if (gi && intensity(cur.weight) < 0.001f) want = Q_NONE;                     // pathtrace early exit, src/main.cpp:118
-			else {
-				tl.add(HC_RAYCASTS);
-				if (cur.depth > S.settings.max_trace_depth) {                            // src/main.cpp:65: black
-					want = Q_NONE;
-					if (!gi && top > 0) { cur = stack[--top]; want = Q_CLOSEST; continue; }
-				}
+			if (gi && intensity(cur.weight) < 0.001f) { want = Q_NONE; continue; }              // pathtrace early exit, src/main.cpp:118
+			tl.add(HC_RAYCASTS);
+			if (cur.depth > S.settings.max_trace_depth) {                                       // src/main.cpp:65: black
+				if (!gi && top > 0) cur = stack[--top];
+				else want = Q_NONE;
+				continue;
 			}
-		} else if (want == Q_SHADOW) {
+		} else {
 			tl.add(HC_SHADOW);
-			d3 A = gi ? hp.ip + hp.norm * 1e-6 : lp;                                     // path: surface -> light (src/main.cpp:155)
-			d3 B = gi ? lp : hp.ip + hp.norm * 1e-6;                                     // direct lighting: light -> surface (src/shading.cpp:81,126)
+			d3 A = gi ? hp.ip + hp.norm * 1e-6 : lp;                                             // path: surface -> light (src/main.cpp:155)
+			d3 B = gi ? lp : hp.ip + hp.norm * 1e-6;                                             // direct lighting: light -> surface (src/shading.cpp:81,126)
 			qo = A;
 			qlimit = dist3(A, B);
 			qd = unit(B - A);
 			qany = true;
 		}
-		if (want == Q_NONE) break;
 
 		// ---- 2. the one traversal site
 		GeomHit bg;
 		double bw;
-		int node = scene_query<COUNT>(S, qo, qd, qlimit, qany, bg, bw, st, tl);
+		int node = scene_query<COUNT, F>(S, qo, qd, qlimit, qany, bg, bw, st, tl);
 
 		// ---- 3. consume the answer
-		bool shade_next = false;   // run the shader work list
+		bool run_shaders = false;   // Whitted: continue with the shader work list of the current hit
+		bool path_vertex = false;   // path tracing: continue at the current vertex
 		if (want == Q_SHADOW) {
 			bool blocked = node >= 0;
 			for (int k = 0; k < S.num_lights && !blocked; k++) {
 				double dd = qlimit;
 				if (light_query(S.lights[k], qo, qd, dd)) blocked = true;
 			}
-			const hxr_shader& sh = S.shaders[cur_shader];
-			if (!gi) {
-				if (!blocked) {   // the light sample reaches the surface: Lambert / Phong term (src/shading.cpp:84-85,129-141)
-					const hxr_light& L = S.lights[li];
-					d3 to_ip = hp.ip - lp;
-					double d2 = len2(to_ip);
-					float lt = (float)fmax(0.0, dot(hp.norm, unit(-to_ip)));
-					if (sh.type == HXR_SHADER_PHONG) {
-						d3 from_light = unit(hp.ip - lp);
-						d3 refl = reflect3(from_light, faceforward(from_light, hp.norm));
-						float cg = (float)dot(-cur.d, refl);
-						if (cg > 0) sum = sum + (ldf(sh.specular) * lc) * powf(cg, sh.exponent);
-					}
-					sum = sum + (base * lc) * (float)(lt * L.power / d2);
-				}
-				ls++;
-				shade_next = true;
-			} else {
-				if (!blocked) {   // explicit light sampling of the path tracer (src/main.cpp:157-168)
-					const hxr_light& L = S.lights[li];
-					d3 w_out = unit(lp - hp.ip);
-					f3 ev = mkf(1, 0, 0);   // BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
-					if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG)
-						ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, hp.norm));
-					else if (sh.type == HXR_SHADER_REFLECTION)
-						ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
-					else if (sh.type == HXR_SHADER_REFRACTION)
-						ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.99999999 ? ldf(sh.color) : mkf(0, 0, 0);
-					f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
-					if (intensity(from_light) > 0) {
-						float p_choose = 1.0f / (float)S.num_lights;
-						float p_hit = (float)(1.0f / light_solid_angle(L, hp.ip));
-						acc = acc + fdiv(from_light * cur.weight, p_choose * p_hit);
+			if (!blocked) {
+				HXR_WATERFALL(cur_shader, u_sh) HXR_WATERFALL(li, u_li) {
+					const hxr_shader& sh = S.shaders[u_sh];
+					const hxr_light& L = S.lights[u_li];
+					if (!gi) {   // the light sample reaches the surface: Lambert / Phong term (src/shading.cpp:84-85,129-141)
+						d3 to_ip = hp.ip - lp;
+						double d2 = len2(to_ip);
+						float lt = (float)fmax(0.0, dot(hp.norm, unit(-to_ip)));
+						if (sh.type == HXR_SHADER_PHONG) {
+							d3 from_light = unit(hp.ip - lp);
+							d3 refl = reflect3(from_light, faceforward(from_light, hp.norm));
+							float cg = (float)dot(-cur.d, refl);
+							if (cg > 0) sum = sum + (ldf(sh.specular) * lc) * powf(cg, sh.exponent);
+						}
+						sum = sum + (base * lc) * (float)(lt * L.power / d2);
+					} else {     // explicit light sampling of the path tracer (src/main.cpp:157-168)
+						d3 w_out = unit(lp - hp.ip);
+						f3 ev = mkf(1, 0, 0);   // BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
+						if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG)
+							ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, hp.norm));
+						else if (sh.type == HXR_SHADER_REFLECTION)
+							ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
+						else if (sh.type == HXR_SHADER_REFRACTION)
+							ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.99999999 ? ldf(sh.color) : mkf(0, 0, 0);
+						f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
+						if (intensity(from_light) > 0) {
+							float p_choose = 1.0f / (float)S.num_lights;
+							float p_hit = (float)(1.0f / light_solid_angle(L, hp.ip));
+							acc = acc + fdiv(from_light * cur.weight, p_choose * p_hit);
+						}
 					}
 				}
-				in_lights = false;
-				shade_next = true;   // continue the path below
 			}
+			if (!gi) { ls++; run_shaders = true; }
+			else { in_lights = false; path_vertex = true; }
 		} else {   // Q_CLOSEST: the rest of TraceContext::raycast (src/main.cpp:76-103)
 			bool lit = false;
 			f3 lcol = mkf(0, 0, 0);
@@ -935,184 +991,197 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 				if (side == -1) { lit = true; lcol = mkf(0, 0, 0); }
 				else if (side == 1) { lit = true; lcol = (ldf(L.color) * L.power) * L.scale_factor; }
 			}
-			bool ended = true;
-			f3 early = mkf(0, 0, 0);
-			if (lit) early = (cur.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lcol;
-			else if (bw >= HXR_INF) early = S.environment.present ? environment_lookup<COUNT>(S, qd, tl) : ldf(S.settings.background);
-			else ended = false;
-			if (ended) {
+			if (lit || bw >= HXR_INF) {   // the ray ends here
+				f3 early;
+				if (lit) early = (cur.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lcol;
+				else early = S.environment.present ? environment_lookup<COUNT>(S, qd, tl) : ldf(S.settings.background);
 				acc = acc + early * cur.weight;
-				if (gi) want = Q_NONE;
-				else if (top > 0) { cur = stack[--top]; want = Q_CLOSEST; }
+				if (!gi && top > 0) cur = stack[--top];
 				else want = Q_NONE;
-				if (want == Q_NONE) break;
-				continue;
-			}
-			Surface sf;
-			surface_of<COUNT>(S, node, qo, qd, bg, bw, sf, tl);
-			int bump = S.nodes[node].bump;
-			if (bump >= 0) texture_bump<COUNT>(S, bump, sf, tl);
-			hp.ip = sf.ip;
-			hp.norm = sf.norm;
-			hp.u = sf.u;
-			hp.v = sf.v;
-			if (!gi) {
-				stop = 0;
-				sh_stack[stop] = S.nodes[node].shader;
-				w_stack[stop++] = cur.weight;
-				in_lights = false;
 			} else {
-				cur_shader = S.nodes[node].shader;
-				in_lights = true;   // "before the light sample"
+				HXR_WATERFALL(node, u_node) {
+					Surface sf;
+					surface_of<COUNT, F>(S, u_node, qo, qd, bg, bw, sf, tl);
+					int bump = S.nodes[u_node].bump;
+					if (bump >= 0) texture_bump<COUNT>(S, bump, sf, tl);
+					hp.ip = sf.ip;
+					hp.norm = sf.norm;
+					hp.u = sf.u;
+					hp.v = sf.v;
+					cur_shader = S.nodes[u_node].shader;
+				}
+				if (!gi) {
+					stop = 0;
+					sh_stack[stop] = cur_shader;
+					w_stack[stop++] = cur.weight;
+					in_lights = false;
+					run_shaders = true;
+				} else {
+					in_lights = true;   // "before the light sample"
+					path_vertex = true;
+				}
 			}
-			shade_next = true;
 		}
 
-		if (!shade_next) continue;
-		Surface sfl;   // texture_sample() reads u, v, norm
-		sfl.ip = hp.ip; sfl.norm = hp.norm; sfl.u = hp.u; sfl.v = hp.v;
-
-		if (gi) {
+		if (gi && path_vertex) {
 			// ---- path tracing: one vertex = [light sample] then spawn (src/main.cpp:122-168)
-			const hxr_shader& sh = S.shaders[cur_shader];
-			const bool diffuse = sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG;
-			// BRDF::spawnRay must succeed first (pdf <= 0 ends the path before any light sampling, src/main.cpp:129-130)
-			d3 refr_dir = mk3(0, 0, 0);
-			bool spawn_ok = diffuse || sh.type == HXR_SHADER_REFLECTION;
-			if (sh.type == HXR_SHADER_REFRACTION)
-				spawn_ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), refr_dir) : refract_dir(cur.d, -hp.norm, (float)sh.ior, refr_dir);
-			if (!spawn_ok) break;
-			if (in_lights) {   // first visit of this vertex: try the explicit light sample
-				in_lights = false;
-				if (diffuse) base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
-				if (S.num_lights > 0) {
-					HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_PICK);
-					li = (int)hxr_below(pick.w0, (uint32_t)S.num_lights);
-					const hxr_light& L = S.lights[li];
-					if (light_solid_angle(L, hp.ip) > 0) {
-						int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples(L));
-						double j1, j2;
-						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_JITTER), j1, j2);
-						f3 unused;
-						light_sample(L, idx, hp.ip, j1, j2, lp, unused);
-						want = Q_SHADOW;
-						continue;
+			Surface sfl;   // texture_sample() reads u, v, norm
+			sfl.ip = hp.ip; sfl.norm = hp.norm; sfl.u = hp.u; sfl.v = hp.v;
+			bool ask_shadow = false, dead = false;
+			RayItem nx = cur;
+			HXR_WATERFALL(cur_shader, u_sh) {
+				const hxr_shader& sh = S.shaders[u_sh];
+				const bool diffuse = sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG;
+				// BRDF::spawnRay must succeed first (pdf <= 0 ends the path before any light sampling, src/main.cpp:129-130)
+				d3 refr_dir = mk3(0, 0, 0);
+				bool spawn_ok = diffuse || sh.type == HXR_SHADER_REFLECTION;
+				if (sh.type == HXR_SHADER_REFRACTION)
+					spawn_ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), refr_dir) : refract_dir(cur.d, -hp.norm, (float)sh.ior, refr_dir);
+				if (!spawn_ok) dead = true;
+				else {
+					if (in_lights) {   // first visit of this vertex: try the explicit light sample
+						in_lights = false;
+						if (diffuse) base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
+						if (S.num_lights > 0) {
+							HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_PICK);
+							li = (int)hxr_below(pick.w0, (uint32_t)S.num_lights);
+							HXR_WATERFALL(li, u_li) {
+								const hxr_light& L = S.lights[u_li];
+								if (light_solid_angle(L, hp.ip) > 0) {
+									int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples(L));
+									double j1, j2;
+									hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_JITTER), j1, j2);
+									f3 unused;
+									light_sample(L, idx, hp.ip, j1, j2, lp, unused);
+									ask_shadow = true;
+								}
+							}
+						}
+					}
+					if (!ask_shadow) {
+						// spawn the next ray: Lambert src/shading.cpp:99-109, Reflection :196-205, Refraction :241-263
+						nx.depth = cur.depth + 1;
+						nx.key = hxr_child_key(cur.key, u_sh, 0);
+						f3 bc;
+						float pdf;
+						if (diffuse) {
+							d3 N = faceforward(cur.d, hp.norm);
+							nx.o = hp.ip + N * 1e-6;
+							double u, v;
+							hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_HEMISPHERE), u, v);
+							nx.d = hemisphere(u, v, N);
+							nx.flags |= HXR_RF_GI_DIFFUSE;
+							bc = (base * (float)(1 / HXR_PI)) * (float)dot(nx.d, N);
+							pdf = (float)(1 / (2 * HXR_PI));
+						} else if (sh.type == HXR_SHADER_REFLECTION) {
+							d3 N = faceforward(cur.d, hp.norm);
+							nx.o = hp.ip + N * 1e-6;
+							nx.d = reflect3(cur.d, N);
+							nx.flags &= ~HXR_RF_GI_DIFFUSE;
+							bc = ldf(sh.color) * 1e+6f;
+							pdf = 1e+6f;
+						} else {
+							nx.o = hp.ip - faceforward(cur.d, hp.norm) * 0.000001;
+							nx.d = refr_dir;
+							nx.flags &= ~HXR_RF_GI_DIFFUSE;
+							bc = ldf(sh.color) * 1e+6f;
+							pdf = 1e+6f;
+						}
+						nx.weight = fdiv(cur.weight * bc, pdf);
 					}
 				}
 			}
-			// spawn the next ray: Lambert src/shading.cpp:99-109, Reflection :196-205, Refraction :241-263
-			RayItem nx = cur;
-			nx.depth = cur.depth + 1;
-			nx.key = hxr_child_key(cur.key, cur_shader, 0);
-			f3 bc;
-			float pdf;
-			if (diffuse) {
-				d3 N = faceforward(cur.d, hp.norm);
-				nx.o = hp.ip + N * 1e-6;
-				double u, v;
-				hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_HEMISPHERE), u, v);
-				nx.d = hemisphere(u, v, N);
-				nx.flags |= HXR_RF_GI_DIFFUSE;
-				bc = (base * (float)(1 / HXR_PI)) * (float)dot(nx.d, N);
-				pdf = (float)(1 / (2 * HXR_PI));
-			} else if (sh.type == HXR_SHADER_REFLECTION) {
-				d3 N = faceforward(cur.d, hp.norm);
-				nx.o = hp.ip + N * 1e-6;
-				nx.d = reflect3(cur.d, N);
-				nx.flags &= ~HXR_RF_GI_DIFFUSE;
-				bc = ldf(sh.color) * 1e+6f;
-				pdf = 1e+6f;
-			} else {
-				nx.o = hp.ip - faceforward(cur.d, hp.norm) * 0.000001;
-				nx.d = refr_dir;
-				nx.flags &= ~HXR_RF_GI_DIFFUSE;
-				bc = ldf(sh.color) * 1e+6f;
-				pdf = 1e+6f;
-			}
-			nx.weight = fdiv(cur.weight * bc, pdf);
-			cur = nx;
-			want = Q_CLOSEST;
-			continue;
+			if (dead) want = Q_NONE;
+			else if (ask_shadow) want = Q_SHADOW;
+			else { cur = nx; want = Q_CLOSEST; }
 		}
 
-		// ---- Whitted: run the shader work list until a light sample needs a shadow ray or the list is empty
-		for (;;) {
-			if (in_lights) {   // Lambert / Phong light loops (src/shading.cpp:74-88,119-142)
-				const hxr_shader& sh = S.shaders[cur_shader];
-				bool asked = false;
-				while (li < S.num_lights) {
-					const hxr_light& L = S.lights[li];
-					int n = light_num_samples(L);
-					if (ls < n) {
-						double j1 = 0, j2 = 0;
-						if (L.type == HXR_LIGHT_RECT)
-							hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)li * 4096u + (uint32_t)ls), j1, j2);
-						light_sample(L, ls, hp.ip, j1, j2, lp, lc);
-						if (is_zero(lc)) { ls++; continue; }
-						asked = true;
-						break;
-					}
-					direct = direct + fdiv(sum, (float)n);
-					sum = mkf(0, 0, 0);
-					li++;
-					ls = 0;
-				}
-				if (asked) { want = Q_SHADOW; break; }
-				acc = acc + (direct + base * ldf(S.settings.ambient)) * cur_w;
-				in_lights = false;
-				(void)sh;
-			}
-			if (stop == 0) {   // this hit is done: next pending ray
-				if (top > 0) { cur = stack[--top]; want = Q_CLOSEST; }
-				else want = Q_NONE;
-				break;
-			}
-			int si = sh_stack[--stop];
-			f3 w = w_stack[stop];
-			const hxr_shader& sh = S.shaders[si];
-			switch (sh.type) {
-				case HXR_SHADER_LAMBERT:
-				case HXR_SHADER_PHONG:
-					cur_shader = si;
-					cur_w = w;
-					base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
-					direct = mkf(0, 0, 0);
-					sum = mkf(0, 0, 0);
-					li = 0;
-					ls = 0;
-					in_lights = true;
-					break;
-				case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
-				case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy is rejected at create time)
-					d3 n = faceforward(cur.d, hp.norm);
-					if (top < HXR_RAY_STACK)
-						stack[top++] = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, si, 0)};
-					break;
-				}
-				case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
-					d3 out;
-					bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
-					if (ok && top < HXR_RAY_STACK)
-						stack[top++] = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, si, 0)};
-					break;
-				}
-				case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
-					f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
-					for (int i = sh.num_layers - 1; i >= 0; i--) {
-						const hxr_layer& Ly = S.layers[sh.first_layer + i];
-						f3 blend = Ly.texture >= 0 ? texture_sample<COUNT>(S, Ly.texture, cur.d, sfl, tl) : ldf(Ly.blend);
-						if (stop < HXR_SHADER_STACK) {
-							sh_stack[stop] = Ly.shader;
-							w_stack[stop++] = (w * blend) * rem;
+		if (!gi && run_shaders) {
+			// ---- Whitted: run the shader work list until a light sample needs a shadow ray or the list is empty
+			Surface sfl;
+			sfl.ip = hp.ip; sfl.norm = hp.norm; sfl.u = hp.u; sfl.v = hp.v;
+			bool settled = false;   // this lane knows what it wants next
+			while (!settled) {
+				if (in_lights) {   // Lambert / Phong light loops (src/shading.cpp:74-88,119-142)
+					bool asked = false;
+					while (li < S.num_lights && !asked) {
+						HXR_WATERFALL(li, u_li) {
+							const hxr_light& L = S.lights[u_li];
+							int n = light_num_samples(L);
+							if (ls < n) {
+								double j1 = 0, j2 = 0;
+								if (L.type == HXR_LIGHT_RECT)
+									hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)u_li * 4096u + (uint32_t)ls), j1, j2);
+								light_sample(L, ls, hp.ip, j1, j2, lp, lc);
+								if (is_zero(lc)) ls++;
+								else asked = true;
+							} else {
+								direct = direct + fdiv(sum, (float)n);
+								sum = mkf(0, 0, 0);
+								li++;
+								ls = 0;
+							}
 						}
-						rem = rem * (mkf(1, 1, 1) - blend);
 					}
-					break;
+					if (asked) { want = Q_SHADOW; settled = true; }
+					else {
+						acc = acc + (direct + base * ldf(S.settings.ambient)) * cur_w;
+						in_lights = false;
+					}
+				} else if (stop == 0) {   // this hit is done: next pending ray
+					if (top > 0) { cur = stack[--top]; want = Q_CLOSEST; }
+					else want = Q_NONE;
+					settled = true;
+				} else {
+					int si = sh_stack[--stop];
+					f3 w = w_stack[stop];
+					HXR_WATERFALL(si, u_si) {
+						const hxr_shader& sh = S.shaders[u_si];
+						switch (sh.type) {
+							case HXR_SHADER_LAMBERT:
+							case HXR_SHADER_PHONG:
+								cur_shader = u_si;
+								cur_w = w;
+								base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
+								direct = mkf(0, 0, 0);
+								sum = mkf(0, 0, 0);
+								li = 0;
+								ls = 0;
+								in_lights = true;
+								break;
+							case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
+							case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy is rejected at create time)
+								d3 n = faceforward(cur.d, hp.norm);
+								if (top < HXR_RAY_STACK)
+									stack[top++] = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+								break;
+							}
+							case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
+								d3 out;
+								bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
+								if (ok && top < HXR_RAY_STACK)
+									stack[top++] = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+								break;
+							}
+							case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
+								f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
+								for (int i = sh.num_layers - 1; i >= 0; i--) {
+									const hxr_layer& Ly = S.layers[sh.first_layer + i];
+									f3 blend = Ly.texture >= 0 ? texture_sample<COUNT>(S, Ly.texture, cur.d, sfl, tl) : ldf(Ly.blend);
+									if (stop < HXR_SHADER_STACK) {
+										sh_stack[stop] = Ly.shader;
+										w_stack[stop++] = (w * blend) * rem;
+									}
+									rem = rem * (mkf(1, 1, 1) - blend);
+								}
+								break;
+							}
+							default: break;
+						}
+					}
 				}
-				default: break;
 			}
 		}
-		if (want == Q_NONE) break;
 	}
 	return acc;
 }
@@ -1136,7 +1205,7 @@ HXR_DEV void camera_ray(const HxrSceneDev& S, int W, int H, double x, double y, 
 	}
 }
 
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
 {
 	double lu = 0, lv = 0;
@@ -1152,12 +1221,12 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	d3 o, d;
 	if (S.camera.stereo_separation == 0.0) {
 		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
-		return trace_rays<COUNT>(S, o, d, rc, st, tl);
+		return trace_rays<COUNT, F>(S, o, d, rc, st, tl);
 	}
 	f3 eye[2];
 	for (int e = 0; e < 2; e++) {   // anaglyph pair (src/main.cpp:237-247)
 		camera_ray(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
-		eye[e] = trace_rays<COUNT>(S, o, d, rc, st, tl);
+		eye[e] = trace_rays<COUNT, F>(S, o, d, rc, st, tl);
 	}
 	float ml = intensity(eye[0]), mr = intensity(eye[1]);
 	return mkf(ml + (eye[0].x - ml) * 0.3f, mr + (eye[1].y - mr) * 0.3f, mr + (eye[1].z - mr) * 0.3f);
@@ -1206,11 +1275,18 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // the render kernel: persistent wavefronts, one ray packet (64 camera samples) per dispenser ticket
 // ------------------------------------------------------------------------------------------------
 #define HXR_BLOCK 256
+#ifndef HXR_SHARDS
+#define HXR_SHARDS 8          // dispenser counters (power of two)
+#endif
+#define HXR_SHARD_STRIDE 32   // uint32 between two counters: one 128-B line each
+#ifndef HXR_BATCH
+#define HXR_BATCH 1           // packets per ticket (larger batches unbalance the waves: expensive packets are spatially clustered)
+#endif
 #ifndef HXR_MIN_WAVES
 #define HXR_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for
 #endif
 
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
     const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
@@ -1243,11 +1319,33 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 	const int rounds = (spp + 63) / 64;
 	// pass 3 sizes itself from the device-side count of flagged pixels (no host round trip between the passes)
 	const uint32_t num_chunks = P.mode == 2 ? ((uint32_t)*P.aa_count + (uint32_t)ppc - 1u) / (uint32_t)ppc : P.num_chunks;
+	// Packet dispenser.  One device-scope counter saturates near 88 tickets/us (MI355X_MICROARCH.md, row
+	// "dequeue") -- 518,400 single-packet tickets of the headline frame would cost 6 ms by themselves -- so the
+	// packets are split into HXR_SHARDS contiguous ranges with a counter each (one per XCD under the
+	// dispatcher's round-robin placement, a speed matter only), and a ticket is a batch of HXR_BATCH packets.
+	// A wave drains its home range, then helps with the others.
+	const uint32_t per_shard = ((num_chunks + HXR_SHARDS * HXR_BATCH - 1) / (HXR_SHARDS * HXR_BATCH)) * HXR_BATCH;
+	uint32_t shard = blockIdx.x & (HXR_SHARDS - 1), shards_done = 0, batch_pos = 0, batch_end = 0;
 	for (;;) {
-		uint32_t chunk = 0;
-		if (lane == 0) chunk = atomicAdd(P.work_counter, 1u);
-		chunk = __builtin_amdgcn_readfirstlane(chunk);
-		if (chunk >= num_chunks) break;
+		if (batch_pos >= batch_end) {
+			bool got = false;
+			while (shards_done < HXR_SHARDS) {
+				uint32_t t = 0;
+				if (lane == 0) t = atomicAdd(P.work_counter + shard * HXR_SHARD_STRIDE, (uint32_t)HXR_BATCH);
+				t = __builtin_amdgcn_readfirstlane(t);
+				const uint32_t lo = shard * per_shard, hi = min(lo + per_shard, num_chunks);
+				if (lo < hi && t < hi - lo) {
+					batch_pos = lo + t;
+					batch_end = min(batch_pos + HXR_BATCH, hi);
+					got = true;
+					break;
+				}
+				shard = (shard + 1) & (HXR_SHARDS - 1);
+				shards_done++;
+			}
+			if (!got) break;
+		}
+		const uint32_t chunk = batch_pos++;
 		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
 		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
 		bool live = slot < ppc;
@@ -1287,7 +1385,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 					sx = (double)((float)x + kx[s]);
 					sy = (double)((float)y + ky[s]);
 				}
-				f3 c = trace_sample<COUNT>(S, P.W, P.H, sx, sy, rc, lds_stack[wave], tl);
+				f3 c = trace_sample<COUNT, F>(S, P.W, P.H, sx, sy, rc, lds_stack[wave], tl);
 				sum = (rd == 0) ? c : sum + c;
 			}
 		}

@@ -18,8 +18,10 @@ from oracle_binding import oracle_render
 pytestmark = pytest.mark.gpu
 
 RMS_BAR = 1e-4   # BASELINE.json north_star: "within 1e-4 per-channel RMS"
+# per-ray work counters that must equal the oracle's (= the reference's per-ray call counts); `box_test_mismatch`
+# counts box tests whose slab form disagreed with the literal BBox::testIntersect form (instrumented build)
 EXACT_COUNTERS = ("camera_samples", "raycasts", "shadow_queries", "node_tests", "bbox_tests", "kd_visits", "leaf_indices", "tri_tests",
-                  "tex_bilinear", "env_bilinear", "hf_calls", "aa_pixels")
+                  "tex_bilinear", "env_bilinear", "hf_calls", "aa_pixels", "box_test_mismatch")
 
 
 def rms(a, b):
