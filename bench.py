@@ -31,9 +31,9 @@ WORKLOADS = {
     "meshes_aa": ("meshes.hexray", dict(width=1920, height=1080),
                   "data/meshes.hexray 1920x1080 adaptive 5-tap AA (as shipped; renderWithoutMonteCarlo)"),
     "simple1": ("simple.hexray", dict(width=1920, height=1080, want_aa=False),
-                "data/simple.hexray 1920x1080 x 1 spp (EXR cubemap not decoded: black environment)"),
+                "data/simple.hexray 1920x1080 x 1 spp"),
     "heightfield16": ("heightfield.hexray", dict(width=1920, height=1080, dof=True, num_samples=16),
-                      "data/heightfield.hexray 1920x1080 x 16 spp (EXR cubemap not decoded: black environment)"),
+                      "data/heightfield.hexray 1920x1080 x 16 spp (Camera dof on, numSamples 16)"),
     "smallpt256": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=256), "data/smallpt.hexray 1920x1080 x 256 paths"),
     "smallpt16": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=16), "data/smallpt.hexray 1920x1080 x 16 paths"),
 }

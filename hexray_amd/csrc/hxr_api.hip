@@ -115,8 +115,15 @@ int validate(const hxr_scene_desc* d)
 		}
 		const hxr_geometry& g = d->geometries[n.geometry];
 		if (g.type == HXR_GEOM_CSG_UNION || g.type == HXR_GEOM_CSG_INTER || g.type == HXR_GEOM_CSG_DIFF) {
-			set_err("CSG geometry (node %lld) is not rendered by this build", (long long)i);
-			return HXR_E_UNSUPPORTED;
+			for (int side = 0; side < 2; side++) {
+				int op = side ? g.right : g.left;
+				if (op < 0 || op >= d->num_geometries) { set_err("CSG operand outside the geometry table"); return HXR_E_INVALID; }
+				int t = d->geometries[op].type;
+				if (t != HXR_GEOM_PLANE && t != HXR_GEOM_SPHERE && t != HXR_GEOM_CUBE) {
+					set_err("CSG (node %lld) over a mesh, heightfield or another CSG is not rendered by this build", (long long)i);
+					return HXR_E_UNSUPPORTED;
+				}
+			}
 		}
 		if (g.type == HXR_GEOM_MESH && (g.ref < 0 || g.ref >= d->num_meshes)) { set_err("bad mesh reference"); return HXR_E_INVALID; }
 		if (g.type == HXR_GEOM_HEIGHTFIELD && (g.ref < 0 || g.ref >= d->num_heightfields)) { set_err("bad heightfield reference"); return HXR_E_INVALID; }
@@ -124,7 +131,6 @@ int validate(const hxr_scene_desc* d)
 		bool glossy = false, cyclic = false;
 		shader_fanout(d, n.shader, 0, rays, pending, glossy, cyclic);
 		if (cyclic) { set_err("Layered shaders of node %lld refer to themselves", (long long)i); return HXR_E_UNSUPPORTED; }
-		if (glossy) { set_err("glossy Reflection (node %lld) is not rendered by this build", (long long)i); return HXR_E_UNSUPPORTED; }
 		if (pending > HXR_SHADER_STACK) { set_err("Layered shader of node %lld is wider than %d entries", (long long)i, HXR_SHADER_STACK); return HXR_E_UNSUPPORTED; }
 		long need = rays <= 1 ? 2 : (long)(d->settings.max_trace_depth + 1) * (rays - 1) + 2;
 		if (need > HXR_RAY_STACK) {
@@ -289,13 +295,13 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		const HxrSceneDev& V = s->host_view;
 #define HXR_LAUNCH(CNT, FEAT)                                                                                                                   \
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, \
-	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, L)
+	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, V.geometries, L)
 #define HXR_LAUNCH_F(FEAT)                                                  \
 	do {                                                                    \
 		if (counters) HXR_LAUNCH(true, FEAT); else HXR_LAUNCH(false, FEAT); \
 	} while (0)
 		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h)
-		const unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE);
+		const unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
 		const bool gi = s->settings.gi != 0;
 		if (!gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH);
 		else if (!gi && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD);
@@ -348,6 +354,13 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	L.counters = counters ? s->d_counters : nullptr;
 	const uint32_t tile_pixels = (uint32_t)p.ntiles * (uint32_t)(p.tile * p.tile);
 
+	if (p.mode == HXR_MODE_MONTE_CARLO && s->camera.dof && s->camera.auto_focus) {
+		const HxrSceneDev& V = s->host_view;
+		double* focal = (double*)((char*)s->dev + offsetof(HxrSceneDev, camera) + offsetof(hxr_camera, focal_plane_dist));
+		hipLaunchKernelGGL(hxr_autofocus_kernel, dim3(1), dim3(64), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.geometries, V.kd, V.hot, V.hot_ids, p.W,
+		                   p.H, focal);
+		HIP_TRY(hipGetLastError());
+	}
 	if (p.mode == HXR_MODE_MONTE_CARLO || p.mode == HXR_MODE_SINGLE) {
 		L.mode = p.mode == HXR_MODE_MONTE_CARLO ? 1 : 0;
 		L.spp = p.spp;
@@ -535,6 +548,7 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		else if (g.type == HXR_GEOM_HEIGHTFIELD) s->features |= HXR_F_HEIGHTFIELD;
 		else if (g.type == HXR_GEOM_SPHERE) s->features |= HXR_F_SPHERE;
 		else if (g.type == HXR_GEOM_CUBE) s->features |= HXR_F_CUBE;
+		else if (g.type >= HXR_GEOM_CSG_UNION && g.type <= HXR_GEOM_CSG_DIFF) s->features |= HXR_F_EXTRA;
 		o.geom_type = g.type;
 		o.geom = n.geometry;
 		o.ref = g.ref;
@@ -544,6 +558,8 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 	}
 	if (s->arena.upload(nodes.data(), nodes.size(), &V.nodes)) return fail();
 	if (s->arena.upload(d->geometries, (size_t)d->num_geometries, &V.geometries)) return fail();
+	for (int64_t i = 0; i < d->num_shaders; i++)
+		if (d->shaders[i].type == HXR_SHADER_REFLECTION && d->shaders[i].glossiness < 1.0f) s->features |= HXR_F_EXTRA;
 	if (s->arena.upload(d->textures, (size_t)d->num_textures, &V.textures)) return fail();
 	if (s->arena.upload(d->shaders, (size_t)d->num_shaders, &V.shaders)) return fail();
 	if (s->arena.upload(d->layers, (size_t)d->num_layers, &V.layers)) return fail();

@@ -37,7 +37,8 @@
 enum : unsigned {
 	HXR_F_MESH = 1u, HXR_F_HEIGHTFIELD = 2u, HXR_F_SPHERE = 4u, HXR_F_CUBE = 8u,   // geometry kinds besides Plane
 	HXR_F_GI = 16u,                                                                 // pathtrace() instead of raytrace()
-	HXR_F_ALL = 31u
+	HXR_F_EXTRA = 32u,                                                              // CSG geometry and glossy Reflection
+	HXR_F_ALL = 63u
 };
 
 // counters (COUNT builds only); order = hxr_counters
@@ -265,6 +266,101 @@ HXR_DEV bool cube_query(const double* p, d3 o, d3 d, GeomHit& g)   // Cube::inte
 	g.t = best;
 	g.tri = face;
 	return face >= 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSG over analytic operands (CSGUnion / CSGInter / CSGDiff, src/geometry.h:109-136, src/geometry.cpp:149-194)
+// ------------------------------------------------------------------------------------------------
+HXR_DEV bool analytic_query(const hxr_geometry& G, d3 o, d3 d, GeomHit& g)
+{
+	switch (G.type) {
+		case HXR_GEOM_PLANE: return plane_query(G.p, o, d, g);
+		case HXR_GEOM_SPHERE: return sphere_query(G.p, o, d, g);
+		case HXR_GEOM_CUBE: return cube_query(G.p, o, d, g);
+		default: return false;
+	}
+}
+
+// object-space normal of an analytic primitive at the hit described by (o, d, g); also u, v
+HXR_DEV d3 analytic_normal(const hxr_geometry& G, d3 o, d3 d, const GeomHit& g, double& u, double& v)
+{
+	d3 ip = o + d * g.t;
+	if (G.type == HXR_GEOM_PLANE) { u = ip.x; v = ip.z; return mk3(0, (o.y > G.p[0]) ? 1 : -1, 0); }
+	if (G.type == HXR_GEOM_SPHERE) {
+		d3 n = unit(ip - ld3(G.p));
+		double vv = asin(n.y), uu = atan2(n.z, n.x);
+		vv = -(vv / HXR_PI + 0.5f);
+		uu = uu / (2 * HXR_PI) + 0.5f;
+		if (G.p[4] != 1) { uu *= G.p[4]; vv *= G.p[4]; }
+		u = uu; v = vv;
+		return n;
+	}
+	int a = g.tri >> 1;
+	double sg = (g.tri & 1) ? 1 : -1;
+	if (a == 0) { u = ip.y; v = ip.z; } else if (a == 1) { u = ip.x; v = ip.z; } else { u = ip.x; v = ip.y; }
+	return mk3(a == 0 ? sg : 0, a == 1 ? sg : 0, a == 2 ? sg : 0);
+}
+
+#define HXR_CSG_MAX 30   // findAllIntersections re-shoots at most 30 times per operand (src/geometry.cpp:155)
+
+// findAllIntersections (src/geometry.cpp:149-165): distances (from the original origin) of the successive hits
+HXR_DEV int csg_collect(const hxr_geometry& G, d3 o, d3 d, double* dist)
+{
+	d3 start = o;
+	int n = 0;
+	for (int k = 0; k < HXR_CSG_MAX; k++) {
+		GeomHit g;
+		g.t = HXR_INF;
+		g.tri = -1;
+		if (!analytic_query(G, start, d, g)) break;
+		d3 ip = start + d * g.t;
+		dist[n++] = dist3(o, ip);
+		start = ip + d * 1e-6;
+	}
+	return n;
+}
+
+// the k-th hit of findAllIntersections again, this time with its attributes
+HXR_DEV void csg_rehit(const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v)
+{
+	d3 start = o;
+	GeomHit g;
+	for (int i = 0; i <= k; i++) {
+		g.t = HXR_INF;
+		g.tri = -1;
+		analytic_query(G, start, d, g);
+		ip = start + d * g.t;
+		if (i < k) start = ip + d * 1e-6;
+	}
+	norm = analytic_normal(G, start, d, g, u, v);
+}
+
+// CSGBase::intersect (src/geometry.cpp:167-194).  Reports the hit as g.t = distance from the origin and
+// g.tri = operand (bit 0) | ordinal of the operand's hit (bits 1..); surface_of() re-derives its attributes.
+HXR_DEV bool csg_query(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, GeomHit& g)
+{
+	const hxr_geometry& GL = S.geometries[C.left];
+	const hxr_geometry& GR = S.geometries[C.right];
+	double dl[HXR_CSG_MAX], dr[HXR_CSG_MAX];
+	int nl = csg_collect(GL, o, d, dl), nr = csg_collect(GR, o, d, dr);
+	bool inA = nl & 1, inB = nr & 1;
+	auto inside = [&](bool a, bool b) { return C.type == HXR_GEOM_CSG_UNION ? (a || b) : C.type == HXR_GEOM_CSG_INTER ? (a && b) : (a && !b); };
+	const bool initial = inside(inA, inB);
+	// merge the two ascending-by-construction lists in distance order (std::sort of the concatenation, left
+	// entries first: on equal distances the earlier element of the concatenation is not guaranteed to stay first
+	// by std::sort; a stable merge is the oracle's choice as well)
+	int il = 0, ir = 0;
+	while (il < nl || ir < nr) {
+		bool take_left = ir >= nr || (il < nl && dl[il] <= dr[ir]);
+		if (take_left) inA = !inA; else inB = !inB;
+		if (inside(inA, inB) != initial) {
+			g.t = take_left ? dl[il] : dr[ir];
+			g.tri = (take_left ? 0 : 1) | ((take_left ? il : ir) << 1);
+			return true;
+		}
+		if (take_left) il++; else ir++;
+	}
+	return false;
 }
 
 // Per-wave traversal stack in LDS: (node, lanes on whose behalf it is pending).
@@ -548,8 +644,30 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 		case HXR_GEOM_HEIGHTFIELD:
 			if constexpr ((F & HXR_F_HEIGHTFIELD) != 0) return heightfield_query<COUNT>(S.heightfields[N.ref], ol, dl, g, tl);
 			return false;
-		default: return false;   // CSG is rejected at scene creation (HXR_E_UNSUPPORTED)
+		case HXR_GEOM_CSG_UNION:
+		case HXR_GEOM_CSG_INTER:
+		case HXR_GEOM_CSG_DIFF:
+			if constexpr ((F & HXR_F_EXTRA) != 0) return csg_query(S, S.geometries[N.geom], ol, dl, g);
+			return false;
+		default: return false;
 	}
+}
+
+// object-space hit point of a query result: start + dir * dist, except for CSG whose point is the one the
+// operand computed on its k-th re-shoot (src/geometry.cpp:158-161,186)
+template <unsigned F>
+HXR_DEV d3 local_hit_point(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, const GeomHit& g)
+{
+	if constexpr ((F & HXR_F_EXTRA) != 0) {
+		if (N.geom_type >= HXR_GEOM_CSG_UNION && N.geom_type <= HXR_GEOM_CSG_DIFF) {
+			const hxr_geometry& C = S.geometries[N.geom];
+			d3 ip, n;
+			double u, v;
+			csg_rehit(S.geometries[(g.tri & 1) ? C.right : C.left], ol, dl, g.tri >> 1, ip, n, u, v);
+			return ip;
+		}
+	}
+	return ol + dl * g.t;
 }
 
 // Node::intersect (src/geometry.cpp:196-208) up to the world-space distance
@@ -561,7 +679,7 @@ HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, do
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
 	if (!geometry_query<COUNT, F>(S, N, ol, dl, g, st, tl)) return false;
-	d3 ipw = mulm(ol + dl * g.t, N.T.m) + ld3(N.T.offset);
+	d3 ipw = mulm(local_hit_point<F>(S, N, ol, dl, g), N.T.m) + ld3(N.T.offset);
 	wdist = dist3(o, ipw);
 	return true;
 }
@@ -579,7 +697,7 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 	const HxrNodeDev& N = S.nodes[ni];
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
-	d3 ip = ol + dl * g.t;
+	d3 ip = local_hit_point<F>(S, N, ol, dl, g);
 	d3 n = mk3(0, 0, 0);
 	sf.dNdx = mk3(0, 0, 0);
 	sf.dNdy = mk3(0, 0, 0);
@@ -637,6 +755,17 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 			sf.v = ip.z / Hf.H;
 			sf.dNdx = mk3(1, 0, 0);
 			sf.dNdy = mk3(0, 0, 1);
+			break;
+		}
+		case HXR_GEOM_CSG_UNION:
+		case HXR_GEOM_CSG_INTER:
+		case HXR_GEOM_CSG_DIFF: if constexpr ((F & HXR_F_EXTRA) != 0) {
+			const hxr_geometry& C = S.geometries[N.geom];
+			const hxr_geometry& G = S.geometries[(g.tri & 1) ? C.right : C.left];
+			d3 hit;
+			csg_rehit(G, ol, dl, g.tri >> 1, hit, n, sf.u, sf.v);
+			n = faceforward(dl, n);   // src/geometry.cpp:187
+			if (G.type == HXR_GEOM_PLANE) { sf.dNdx = mk3(1, 0, 0); sf.dNdy = mk3(0, 0, 1); }
 			break;
 		}
 		default: break;
@@ -838,6 +967,14 @@ struct RayItem {
 	uint32_t flags, key;
 };
 
+// A pending entry of the per-lane ray stack.  With glossy Reflection compiled in, an entry can also be a
+// GENERATOR: `left` more samples of shader `shader` are still to be shot from r.o (surface point), with r.d the
+// incoming direction and n the face-forwarded normal (Reflection::computeColor, src/shading.cpp:165-184) -- the
+// reference loops over numSamples recursive raytrace() calls; here the loop is unrolled over stack pops.
+template <bool GLOSSY> struct StackItem;
+template <> struct StackItem<false> { RayItem r; };
+template <> struct StackItem<true> { RayItem r; d3 n; int left, shader; };
+
 struct RngCtx {
 	uint64_t seed;
 	uint32_t pixel, sample;
@@ -894,12 +1031,51 @@ template <bool COUNT, unsigned F>
 HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
 {
 	constexpr bool gi = (F & HXR_F_GI) != 0;   // the launcher picks the variant that matches settings.gi
-	RayItem stack[HXR_RAY_STACK];
+	constexpr bool glossy = (F & HXR_F_EXTRA) != 0;
+	StackItem<glossy> stack[HXR_RAY_STACK];
 	int sh_stack[HXR_SHADER_STACK];
 	f3 w_stack[HXR_SHADER_STACK];
 	int top = 0, stop = 0;
 	f3 acc = mkf(0, 0, 0);
 	RayItem cur{o0, d0, mkf(1, 1, 1), 0, 0u, 0u};
+	auto pop_ray = [&]() {   // top > 0: the next pending ray becomes `cur`
+		StackItem<glossy>& e = stack[top - 1];
+		if constexpr (glossy) {
+			if (e.left > 0) {
+				const hxr_shader& sh = S.shaders[e.shader];
+				const int k = sh.num_samples - e.left;
+				const float scaling = powf(10.0f, 2 - 8 * sh.glossiness);
+				// othonormedBasis, src/vector.h:194-207
+				d3 t0 = mk3(0.577350269, 0.577350269, 0.577350269), t1 = mk3(0.267261242, -0.534522484, 0.801783726);
+				d3 tv = fabs(dot(e.n, t0)) > 0.9 ? t1 : t0;
+				d3 bu = unit(cross(tv, e.n));
+				d3 bv = cross(bu, e.n);
+				d3 refl = e.n;
+				for (uint32_t attempt = 0;; attempt++) {   // `do { ... } while (dot(reflected, n) < 0)`, bounded
+					double x = 0, y = 0;
+					uint32_t inner = 0;
+					do {                                   // unitDiskSample, src/util.cpp:101-107, bounded
+						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, e.r.key, HXR_DIM_GLOSSY + (uint32_t)k * 64u + ((attempt * 8u + inner) & 63u)), x, y);
+						x = x * 2 - 1;
+						y = y * 2 - 1;
+						inner++;
+					} while (x * x + y * y > 1 && inner < 8);
+					x *= scaling;
+					y *= scaling;
+					d3 mn = unit(e.n + (bu * x + bv * y));
+					refl = reflect3(e.r.d, mn);
+					if (!(dot(refl, e.n) < 0) || attempt >= 7) break;
+				}
+				cur = e.r;
+				cur.d = refl;
+				cur.key = hxr_child_key(e.r.key, e.shader, (uint32_t)k);
+				if (--e.left == 0) top--;
+				return;
+			}
+		}
+		cur = e.r;
+		top--;
+	};
 	int want = Q_CLOSEST;
 	// context of the hit being shaded
 	HitPoint hp{};
@@ -919,7 +1095,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 			if (gi && intensity(cur.weight) < 0.001f) { want = Q_NONE; continue; }              // pathtrace early exit, src/main.cpp:118
 			tl.add(HC_RAYCASTS);
 			if (cur.depth > S.settings.max_trace_depth) {                                       // src/main.cpp:65: black
-				if (!gi && top > 0) cur = stack[--top];
+				if (!gi && top > 0) pop_ray();
 				else want = Q_NONE;
 				continue;
 			}
@@ -996,7 +1172,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 				if (lit) early = (cur.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lcol;
 				else early = S.environment.present ? environment_lookup<COUNT>(S, qd, tl) : ldf(S.settings.background);
 				acc = acc + early * cur.weight;
-				if (!gi && top > 0) cur = stack[--top];
+				if (!gi && top > 0) pop_ray();
 				else want = Q_NONE;
 			} else {
 				HXR_WATERFALL(node, u_node) {
@@ -1129,7 +1305,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 						in_lights = false;
 					}
 				} else if (stop == 0) {   // this hit is done: next pending ray
-					if (top > 0) { cur = stack[--top]; want = Q_CLOSEST; }
+					if (top > 0) { pop_ray(); want = Q_CLOSEST; }
 					else want = Q_NONE;
 					settled = true;
 				} else {
@@ -1150,17 +1326,33 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 								in_lights = true;
 								break;
 							case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
-							case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy is rejected at create time)
+							case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy: generator entry below)
 								d3 n = faceforward(cur.d, hp.norm);
-								if (top < HXR_RAY_STACK)
-									stack[top++] = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+								if (top < HXR_RAY_STACK) {
+									StackItem<glossy>& e = stack[top++];
+									e.r = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+									if constexpr (glossy) {
+										e.left = 0;
+										if (sh.glossiness < 1.0f) {   // numSamples perturbed mirrors, averaged (src/shading.cpp:165-184)
+											e.r.d = cur.d;
+											e.r.weight = fdiv(ldf(sh.color) * w, (float)sh.num_samples);
+											e.r.key = cur.key;
+											e.n = n;
+											e.left = sh.num_samples;
+											e.shader = u_si;
+										}
+									}
+								}
 								break;
 							}
 							case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
 								d3 out;
 								bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
-								if (ok && top < HXR_RAY_STACK)
-									stack[top++] = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+								if (ok && top < HXR_RAY_STACK) {
+									StackItem<glossy>& e = stack[top++];
+									e.r = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+									if constexpr (glossy) e.left = 0;
+								}
 								break;
 							}
 							case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
@@ -1291,7 +1483,8 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
     const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
     const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights,
-    const HxrKdWide* __restrict__ a_kd, const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids, HxrLaunch P)
+    const HxrKdWide* __restrict__ a_kd, const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids,
+    const hxr_geometry* __restrict__ a_geoms, HxrLaunch P)
 {
 	// The small tables arrive as separate `const __restrict__` kernel arguments: only then can the compiler
 	// prove that the frame / counter stores of this kernel never clobber them, and fetch their wave-uniform
@@ -1308,6 +1501,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 	S.kd = a_kd;
 	S.hot = a_hot;
 	S.hot_ids = a_hot_ids;
+	S.geometries = a_geoms;
 	__shared__ float lds_rgb[HXR_BLOCK / 64][64][3];
 	__shared__ WaveStack lds_stack[HXR_BLOCK / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1420,6 +1614,32 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 			if (lane == 0 && v) atomicAdd(&P.counters[i], (unsigned long long)v);
 		}
 	}
+}
+
+// Autofocus probe of renderWithMonteCarlo (src/main.cpp:350-362): the distance to the closest node along the
+// ray through the frame centre becomes the focal plane distance.  One wavefront, every lane the same ray.
+__global__ __launch_bounds__(64) void hxr_autofocus_kernel(
+    const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
+    const HxrHeightfieldDev* __restrict__ a_hfs, const hxr_geometry* __restrict__ a_geoms, const HxrKdWide* __restrict__ a_kd,
+    const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids, int W, int H, double* focal_out)
+{
+	__shared__ WaveStack st;
+	HxrSceneDev S = *Sp;
+	S.nodes = a_nodes;
+	S.meshes = a_meshes;
+	S.heightfields = a_hfs;
+	S.geometries = a_geoms;
+	S.kd = a_kd;
+	S.hot = a_hot;
+	S.hot_ids = a_hot_ids;
+	Tally<false> tl;
+	d3 o = ld3(S.camera.pos), tlc = ld3(S.camera.top_left);
+	d3 through = tlc + (ld3(S.camera.top_right) - tlc) * ((W * 0.5) / (double)W) + (ld3(S.camera.bottom_left) - tlc) * ((H * 0.5) / (double)H);
+	d3 d = unit(through - o);
+	GeomHit g;
+	double w;
+	int node = scene_query<false, (HXR_F_ALL & ~HXR_F_GI)>(S, o, d, HXR_INF, false, g, w, st, tl);
+	if (threadIdx.x == 0 && node >= 0 && w < HXR_INF) *focal_out = w;
 }
 
 // detectAApixels, src/main.cpp:192-222: a pixel needs AA when any channel differs from any of its 8

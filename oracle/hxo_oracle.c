@@ -62,6 +62,7 @@ typedef struct {
 	int W, H;
 	uint64_t seed;
 	uint32_t pixel, sample; /* RNG counter words of the camera sample being traced */
+	double focal_plane_dist; /* Camera::focalPlaneDist, possibly replaced by the autofocus probe */
 	hxr_counters cnt;
 } ctx_t;
 
@@ -1035,7 +1036,7 @@ static ray_t camera_ray(const ctx_t* cx, double x, double y, int dof, double lu,
 	r.dir = vunit(vsub(through, r.start));
 	if (stereo != 0) r.start = vadd(r.start, vmul(vld(c->right), stereo * c->stereo_separation));
 	if (dof) {
-		double M = c->focal_plane_dist / vdot(vld(c->front), r.dir);
+		double M = cx->focal_plane_dist / vdot(vld(c->front), r.dir);
 		vec T = vadd(r.start, vmul(r.dir, M));
 		r.start = vadd(vadd(pos, vmul(vld(c->right), lu * c->aperture_size)), vmul(vld(c->up), lv * c->aperture_size));
 		r.dir = vunit_lazy(vsub(T, r.start));
@@ -1107,6 +1108,20 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 		if (spp <= 0) spp = 1;
 	}
 	uint64_t seed = fp->rng_seed;
+	double focal = sc->camera.focal_plane_dist;
+	if (mode == HXR_MODE_MONTE_CARLO && sc->camera.dof && sc->camera.auto_focus) {
+		/* autofocus, src/main.cpp:350-362: distance of the closest node along the ray through the frame centre */
+		ctx_t cx;
+		memset(&cx, 0, sizeof cx);
+		cx.sc = sc; cx.W = W; cx.H = H; cx.focal_plane_dist = focal;
+		ray_t mid = camera_ray(&cx, W * 0.5, H * 0.5, 0, 0, 0, 0);
+		double closest = HXO_INF;
+		for (int64_t i = 0; i < sc->num_nodes; i++) {
+			hit_t h;
+			if (node_hit(&cx, (int)i, &mid, &h) && h.dist < closest) closest = h.dist;
+		}
+		if (closest < HXO_INF) focal = closest;
+	}
 	const int B = 64;
 	int BW = (W - 1) / B + 1, BH = (H - 1) / B + 1, nb = BW * BH;
 	hxr_counters total;
@@ -1116,13 +1131,13 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 #endif
 	unsigned char* flags = NULL;
 
-	if (mode == HXR_MODE_MONTE_CARLO) { /* renderWithMonteCarlo, src/main.cpp:347-384 (autofocus not restated) */
+	if (mode == HXR_MODE_MONTE_CARLO) { /* renderWithMonteCarlo, src/main.cpp:347-384 */
 		float mul = 1.0f / spp;
 #pragma omp parallel
 		{
 			ctx_t cx;
 			memset(&cx, 0, sizeof cx);
-			cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed;
+			cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed; cx.focal_plane_dist = focal;
 #pragma omp for schedule(dynamic, 1)
 			for (int b = 0; b < nb; b++) {
 				int x0 = (b % BW) * B, y0 = (b / BW) * B;
@@ -1149,7 +1164,7 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 		{
 			ctx_t cx;
 			memset(&cx, 0, sizeof cx);
-			cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed;
+			cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed; cx.focal_plane_dist = focal;
 #pragma omp for schedule(dynamic, 1)
 			for (int b = 0; b < nb; b++) {
 				int x0 = (b % BW) * B, y0 = (b / BW) * B;
@@ -1195,7 +1210,7 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 			{
 				ctx_t cx;
 				memset(&cx, 0, sizeof cx);
-				cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed;
+				cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed; cx.focal_plane_dist = focal;
 				float mul = 1.0f / 5;
 #pragma omp for schedule(dynamic, 1)
 				for (int b = 0; b < nb; b++) {
@@ -1299,7 +1314,7 @@ void hxo_camera_ray(const hxr_scene_desc* sc, int W, int H, double x, double y, 
 {
 	ctx_t cx;
 	memset(&cx, 0, sizeof cx);
-	cx.sc = sc; cx.W = W; cx.H = H;
+	cx.sc = sc; cx.W = W; cx.H = H; cx.focal_plane_dist = sc->camera.focal_plane_dist;
 	ray_t r = camera_ray(&cx, x, y, dof, lu, lv, 0);
 	out6[0] = r.start.x; out6[1] = r.start.y; out6[2] = r.start.z;
 	out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;

@@ -101,11 +101,40 @@ def test_camera_update_between_frames(gpu):
 
 
 def test_unsupported_scenes_fail_loudly(gpu):
-    """CSG and glossy reflection are not rendered by this build: creation must fail, not fall back."""
-    for scene in ("kdtree_test.hexray",):
-        hs = hx.HostScene(scene_path(scene))
-        with pytest.raises(hx.HipError, match="not rendered by this build"):
-            hx.DeviceScene(hs)
+    """CSG over anything but analytic primitives is not rendered by this build: creation must fail, not fall back."""
+    nested = "CSGUnion both {\n left floor\n right c0\n}\nNode extra {\n geometry both\n shader lambert\n}\n"
+    hs = hx.HostScene(scene_path("kdtree_test.hexray"), nested)
+    with pytest.raises(hx.HipError, match="not rendered by this build"):
+        hx.DeviceScene(hs)
+
+
+# element classes outside the five configs (SURVEY.md section 8f rank 4): Cube + CSG, glossy Reflection, autofocus,
+# RectLight in direct lighting, path tracing over meshes
+OTHER_SCENES = [
+    ("kdtree_test.hexray", hx.overlay_text(240, 180), dict(), True),                                            # CSGDiff of two cubes + kd mesh
+    ("hw10/bokeh.hexray", hx.overlay_text(160, 120, num_samples=4), dict(), True),                              # CSG + depth of field
+    ("meshes.hexray", hx.overlay_text(96, 72, want_aa=False, extra="GlobalSettings {\nmaxTraceDepth 3\n}\nReflection reflection {\nglossiness 0.6\nnumSamples 3\n}\n"), dict(), True),
+    ("meshes.hexray", hx.overlay_text(160, 120, dof=True, num_samples=4, extra="Camera {\nautoFocus on\n}\n"), dict(), True),
+    ("boxed.hexray", hx.overlay_text(96, 72, want_aa=False), dict(mode=hx.MODE_SINGLE), True),                 # RectLights sampled by Lambert
+    ("cornell_box.hexray", hx.overlay_text(96, 72, num_paths=4), dict(), False),                                # GI over meshes
+    ("hw12/sphtri.hexray", hx.overlay_text(96, 72, num_paths=4, num_samples=4), dict(), False),
+]
+
+
+@pytest.mark.parametrize("scene,ov,fp,exact", OTHER_SCENES)
+def test_other_element_classes_match_oracle(gpu, scene, ov, fp, exact):
+    g, gc, o, oc = both(scene, ov, fp)
+    assert np.all(rms(g, o) <= RMS_BAR), rms(g, o)
+    assert gc["camera_samples"] == oc["camera_samples"] and gc["box_test_mismatch"] == 0
+    if exact:
+        for k in ("raycasts", "shadow_queries", "node_tests", "bbox_tests", "tri_tests"):
+            assert gc[k] == oc[k], (k, gc[k], oc[k])
+
+
+def test_autofocus_changes_the_focal_plane(gpu):
+    a = hx.DeviceScene(hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(160, 120, dof=True, num_samples=4))).render()
+    b = hx.DeviceScene(hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(160, 120, dof=True, num_samples=4, extra="Camera {\nautoFocus on\n}\n"))).render()
+    assert rms(a, b).mean() > 1e-3
 
 
 def test_device_output_sharding_and_assembly(gpu):
