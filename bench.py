@@ -36,6 +36,8 @@ WORKLOADS = {
                       "data/heightfield.hexray 1920x1080 x 16 spp (Camera dof on, numSamples 16)"),
     "smallpt256": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=256), "data/smallpt.hexray 1920x1080 x 256 paths"),
     "smallpt16": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=16), "data/smallpt.hexray 1920x1080 x 16 paths"),
+    # no nodes at all: the fixed per-packet cost (sample generation, camera, reduction, store)
+    "empty16": ("../tests/golden/tiny.hexray", dict(width=1920, height=1080, dof=True, num_samples=16), "empty scene 1920x1080 x 16 spp (overhead probe)"),
 }
 TILE = 32
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)

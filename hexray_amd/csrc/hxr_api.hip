@@ -555,6 +555,46 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		o.shader = n.shader;
 		o.bump = n.bump;
 		memcpy(o.p, g.p, sizeof o.p);
+		// object-space bounds of the geometry, if it has finite ones
+		double lo[3], hi[3];
+		bool bounded = true;
+		if (g.type == HXR_GEOM_MESH) { memcpy(lo, d->meshes[g.ref].bbox_min, sizeof lo); memcpy(hi, d->meshes[g.ref].bbox_max, sizeof hi); }
+		else if (g.type == HXR_GEOM_HEIGHTFIELD) { memcpy(lo, d->heightfields[g.ref].bbox_min, sizeof lo); memcpy(hi, d->heightfields[g.ref].bbox_max, sizeof hi); }
+		else if (g.type == HXR_GEOM_SPHERE) for (int c = 0; c < 3; c++) { lo[c] = g.p[c] - g.p[3]; hi[c] = g.p[c] + g.p[3]; }
+		else if (g.type == HXR_GEOM_CUBE) for (int c = 0; c < 3; c++) { lo[c] = g.p[c] - g.p[3]; hi[c] = g.p[c] + g.p[3]; }
+		else bounded = false;   // planes (possibly unlimited) and CSG are always scanned
+		for (int c = 0; c < 3 && bounded; c++) bounded = std::isfinite(lo[c]) && std::isfinite(hi[c]) && lo[c] <= hi[c];
+		o.cullable = 0;
+		if (bounded) {
+			double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300}, scale = 0;
+			for (int c = 0; c < 3; c++) {   // the reference's own slacks: BBox::inside +-1e-6 (src/bbox.h:80-85), Cube inBounds +-1e-6 (src/geometry.cpp:87-95)
+				double pad = 2e-6 + 1e-9 * std::max(std::fabs(lo[c]), std::fabs(hi[c]));
+				lo[c] -= pad;
+				hi[c] += pad;
+			}
+			for (int corner = 0; corner < 8; corner++) {
+				double pt[3] = {corner & 1 ? hi[0] : lo[0], corner & 2 ? hi[1] : lo[1], corner & 4 ? hi[2] : lo[2]};
+				for (int c = 0; c < 3; c++) {   // p * M + offset
+					double w = pt[0] * n.T.m[0 * 3 + c] + pt[1] * n.T.m[1 * 3 + c] + pt[2] * n.T.m[2 * 3 + c] + n.T.offset[c];
+					wlo[c] = std::min(wlo[c], w);
+					whi[c] = std::max(whi[c], w);
+					scale = std::max(scale, std::fabs(w));
+				}
+			}
+			// sphere around the world box of the 8 transformed corners (it contains the transformed box, which is their convex hull)
+			double r2 = 0;
+			bool ok = true;
+			for (int c = 0; c < 3; c++) {
+				o.cull_lo[c] = 0.5 * (wlo[c] + whi[c]);
+				double h = 0.5 * (whi[c] - wlo[c]);
+				r2 += h * h;
+				ok = ok && std::isfinite(o.cull_lo[c]);
+			}
+			double r = std::sqrt(r2) * (1 + 1e-9) + 1e-9 * (scale + 1.0);   // ~1e7 ulps of margin for the transform and the test's own rounding
+			o.cull_hi[0] = r * r;
+			o.cull_hi[1] = o.cull_hi[2] = 0;
+			o.cullable = (ok && std::isfinite(o.cull_hi[0])) ? 1 : 0;
+		}
 	}
 	if (s->arena.upload(nodes.data(), nodes.size(), &V.nodes)) return fail();
 	if (s->arena.upload(d->geometries, (size_t)d->num_geometries, &V.geometries)) return fail();

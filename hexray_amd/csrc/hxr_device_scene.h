@@ -65,8 +65,14 @@ struct HxrNodeDev {
 	int32_t geom;            // geometry table index (CSG operands refer to it)
 	int32_t ref;             // mesh / heightfield index
 	int32_t shader, bump;
-	int32_t pad_[3];
+	int32_t cullable;        // cull_lo / cull_hi are valid
+	int32_t pad_[2];
 	double p[6];             // analytic parameters of the geometry
+	// World-space sphere that encloses everything a ray must reach to get ANY answer other than "miss" from this
+	// node: it contains the transformed, 1e-6-inflated (BBox::inside slack) bounding box of the geometry, with a
+	// relative safety margin far above FP64 rounding.  A ray that misses it is a miss for the node without
+	// transforming the ray into object space.  cull_lo = centre, cull_hi[0] = squared radius.
+	double cull_lo[3], cull_hi[3];
 };
 
 struct HxrSceneDev {

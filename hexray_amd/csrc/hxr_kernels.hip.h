@@ -676,6 +676,21 @@ HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, do
 {
 	const HxrNodeDev& N = S.nodes[__builtin_amdgcn_readfirstlane(ni)];   // the node scan is wave-uniform: scalar loads
 	tl.add(HC_NODE);
+	if (N.cullable) {
+		// World-space rejection: when NO ray of the wave reaches the node's (inflated) world box, the reference's
+		// Node::intersect would return false for every one of them -- after transforming the ray and, for a mesh,
+		// failing the root BBox::testIntersect (src/mesh.cpp:249), which is counted as if it had been made.
+		// bounding sphere of that box: the ray's line passes farther than the radius from the centre, or the sphere
+		// lies wholly behind the origin (`d` is a unit vector; no division needed)
+		d3 oc = mk3(N.cull_lo[0], N.cull_lo[1], N.cull_lo[2]) - o;   // cull_lo = centre, cull_hi[0] = radius^2
+		double along = dot(oc, d), oc2 = len2(oc), r2 = N.cull_hi[0];
+		bool reach = !(oc2 - along * along > r2) && !(along < 0 && oc2 > r2);
+		if (!__ballot(reach)) {
+			if (N.geom_type == HXR_GEOM_MESH) tl.add(HC_BBOX);
+			if (N.geom_type == HXR_GEOM_HEIGHTFIELD) tl.add(HC_HFCALL);
+			return false;
+		}
+	}
 	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
 	if (!geometry_query<COUNT, F>(S, N, ol, dl, g, st, tl)) return false;
