@@ -68,9 +68,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a box with fewer GPUs than ranks (HXR_BENCH_REHEARSAL=1): every rank renders on GPU 0 and the gather
+    # goes through gloo on host copies.  RCCL refuses two ranks on one device, so this is the only way to run the
+    # sharded pipeline end to end on a single-GPU box; the numbers it prints are not a measurement.
+    rehearsal = os.environ.get("HXR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -101,7 +110,12 @@ def main():
 
         def step():
             ds.render_device(params, local.data_ptr(), 0, stream)
-            gathered = gather_tiles(local, world, rank)
+            if rehearsal:
+                torch.cuda.synchronize()
+                got = gather_tiles(local.cpu(), world, rank)
+                gathered = got.cuda() if rank == 0 else None
+            else:
+                gathered = gather_tiles(local, world, rank)
             if rank == 0:
                 ds.assemble_frame(params, gathered.data_ptr(), slots * TILE * TILE * 12, frame.data_ptr(), W * 12, stream)
 
@@ -123,7 +137,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -143,6 +157,16 @@ def main():
         counters = ds.counters()
     else:
         counters = None
+
+    if world > 1 and rank == 0 and os.environ.get("HXR_BENCH_VERIFY") == "1":
+        # the sharded frame must equal the unsharded one bit for bit (random numbers are keyed on pixel and sample)
+        whole = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        ds.render_device(hx.frame_params(tile_size=TILE), whole.data_ptr(), W * 12, stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(whole, frame))
+        print("sharded frame identical to the single-GPU frame:", same, file=sys.stderr)
+        if not same:
+            raise SystemExit("sharded frame differs from the single-GPU frame")
 
     result = None
     if rank == 0:

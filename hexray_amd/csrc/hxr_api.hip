@@ -156,9 +156,10 @@ int validate(const hxr_scene_desc* d)
 
 // Wide kd records (node box stored in the node) + leaf-ordered hot triangles of one mesh, appended to the
 // scene-wide arrays (see hxr_device_scene.h)
-void append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdWide>& kd, std::vector<HxrTriHot>& hot,
-                        std::vector<int32_t>& ids)
+int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdWide>& kd, std::vector<HxrTriHot>& hot,
+                       std::vector<int32_t>& ids)
 {
+	int max_depth = 0;
 	const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
 	const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
 	const hxr_triangle* tris = d->triangles + m.first_triangle;
@@ -180,14 +181,15 @@ void append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& 
 	};
 	if (!m.has_kd || m.num_kd_nodes == 0) {
 		for (int64_t i = 0; i < m.num_triangles; i++) push_hot((int)i);
-		return;
+		return 0;
 	}
 	const size_t kd0 = kd.size();
 	kd.resize(kd0 + (size_t)m.num_kd_nodes);
-	struct Item { int node; double lo[3], hi[3]; };
+	struct Item { int node; int depth; double lo[3], hi[3]; };
 	std::vector<Item> todo;
 	Item root;
 	root.node = 0;
+	root.depth = 0;
 	for (int c = 0; c < 3; c++) { root.lo[c] = m.bbox_min[c]; root.hi[c] = m.bbox_max[c]; }
 	todo.push_back(root);
 	while (!todo.empty()) {
@@ -208,11 +210,14 @@ void append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& 
 		Item L = it, R = it;   // BBox::split: the children copy the box and replace one bound by the split position
 		L.node = n.first;
 		R.node = n.first + 1;
+		L.depth = R.depth = it.depth + 1;
+		if (L.depth > max_depth) max_depth = L.depth;
 		L.hi[n.axis] = n.split;
 		R.lo[n.axis] = n.split;
 		todo.push_back(R);
 		todo.push_back(L);   // left first, so hot records follow the builder's leaf order
 	}
+	return max_depth;
 }
 
 int ensure(void** p, size_t* have, size_t need)
@@ -503,7 +508,11 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		o.backface_culling = m.backface_culling;
 		o.has_kd = m.has_kd && m.num_kd_nodes > 0;
 		o.num_triangles = (int32_t)m.num_triangles;
-		append_mesh_tables(d, m, o, all_kd, all_hot, all_ids);
+		int depth = append_mesh_tables(d, m, o, all_kd, all_hot, all_ids);
+		if (3 * (depth + 1) > HXR_KD_STACK) {   // the packet walk queues at most three visits per level
+			set_err("kd-tree of mesh %lld is %d levels deep (limit %d)", (long long)i, depth, HXR_KD_STACK / 3 - 1);
+			return fail();
+		}
 		o.tris = d_tris + m.first_triangle;
 		o.vertices = d_f64 + m.first_vertex * 3;
 		o.normals = d_f64 + m.first_normal * 3;
