@@ -320,6 +320,12 @@ class DeviceScene:
         _check(hip_lib().hxr_get_counters(self._s, ctypes.byref(c)), "hxr_get_counters")
         return c.as_dict()
 
+    def counters_raw(self) -> Counters:
+        """The whole hxr_counters record (reserved_ holds the phase clocks of a -DHXR_PHASE_TIMERS build)."""
+        c = Counters()
+        _check(hip_lib().hxr_get_counters(self._s, ctypes.byref(c)), "hxr_get_counters")
+        return c
+
     def last_kernel_ms(self) -> float:
         return hip_lib().hxr_last_kernel_ms(self._s)
 

@@ -154,16 +154,20 @@ int validate(const hxr_scene_desc* d)
 	return 0;
 }
 
-// Wide kd records (node box stored in the node) + leaf-ordered hot triangles of one mesh, appended to the
-// scene-wide arrays (see hxr_device_scene.h)
-int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdWide>& kd, std::vector<HxrTriHot>& hot,
-                       std::vector<int32_t>& ids)
+// Slim kd records + node boxes + leaf-ordered hot triangles of one mesh, appended to the scene-wide arrays
+// (see hxr_device_scene.h)
+int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdSlim>& kd, std::vector<HxrKdBox>& boxes,
+                       std::vector<HxrTriHot>& hot, std::vector<int32_t>& ids)
 {
 	int max_depth = 0;
 	const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
 	const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
 	const hxr_triangle* tris = d->triangles + m.first_triangle;
 	const double* verts = d->f64_pool + m.first_vertex * 3;
+	if (kd.size() % 2 == 0) {   // roots sit at odd global indices: every child pair is then 32-byte aligned
+		kd.push_back(HxrKdSlim{0.0, 0, HXR_KD_LEAF});
+		boxes.push_back(HxrKdBox{{0, 0, 0}, {0, 0, 0}});
+	}
 	o.kd_first = (int32_t)kd.size();
 	o.hot_first = (int32_t)hot.size();
 	const size_t hot0 = hot.size();
@@ -185,6 +189,7 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o
 	}
 	const size_t kd0 = kd.size();
 	kd.resize(kd0 + (size_t)m.num_kd_nodes);
+	boxes.resize(kd0 + (size_t)m.num_kd_nodes);
 	struct Item { int node; int depth; double lo[3], hi[3]; };
 	std::vector<Item> todo;
 	Item root;
@@ -196,8 +201,9 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o
 		Item it = todo.back();
 		todo.pop_back();
 		const hxr_kd_node& n = nodes[it.node];
-		HxrKdWide& r = kd[kd0 + (size_t)it.node];
-		for (int c = 0; c < 3; c++) { r.lo[c] = it.lo[c]; r.hi[c] = it.hi[c]; }
+		HxrKdSlim& r = kd[kd0 + (size_t)it.node];
+		HxrKdBox& rb = boxes[kd0 + (size_t)it.node];
+		for (int c = 0; c < 3; c++) { rb.lo[c] = it.lo[c]; rb.hi[c] = it.hi[c]; }
 		r.split = n.split;
 		if (n.axis == HXR_KD_LEAF) {
 			r.first = (int32_t)(hot.size() - hot0);
@@ -300,7 +306,7 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		const HxrSceneDev& V = s->host_view;
 #define HXR_LAUNCH(CNT, FEAT)                                                                                                                   \
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, \
-	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.hot, V.hot_ids, V.geometries, L)
+	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L)
 #define HXR_LAUNCH_F(FEAT)                                                  \
 	do {                                                                    \
 		if (counters) HXR_LAUNCH(true, FEAT); else HXR_LAUNCH(false, FEAT); \
@@ -350,19 +356,24 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (p.layout == HXR_LAYOUT_FRAME && stride < (size_t)p.W * 12) { set_err("row stride smaller than a row"); return HXR_E_INVALID; }
 	const bool counters = fp->collect_counters != 0;
+#ifdef HXR_PHASE_TIMERS
+	const bool want_counter_buffer = true;    // profiling build: the phase clocks land in hxr_counters.reserved_
+#else
+	const bool want_counter_buffer = counters;
+#endif
 	HIP_TRY(hipMemsetAsync(s->d_work, 0, 1024 * sizeof(uint32_t), st));
-	if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
-	s->counters_valid = counters;
+	if (want_counter_buffer) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
+	s->counters_valid = want_counter_buffer;
 	s->timed = false;
 	HxrLaunch L;
 	fill_launch(s, p, L);
-	L.counters = counters ? s->d_counters : nullptr;
+	L.counters = want_counter_buffer ? s->d_counters : nullptr;
 	const uint32_t tile_pixels = (uint32_t)p.ntiles * (uint32_t)(p.tile * p.tile);
 
 	if (p.mode == HXR_MODE_MONTE_CARLO && s->camera.dof && s->camera.auto_focus) {
 		const HxrSceneDev& V = s->host_view;
 		double* focal = (double*)((char*)s->dev + offsetof(HxrSceneDev, camera) + offsetof(hxr_camera, focal_plane_dist));
-		hipLaunchKernelGGL(hxr_autofocus_kernel, dim3(1), dim3(64), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.geometries, V.kd, V.hot, V.hot_ids, p.W,
+		hipLaunchKernelGGL(hxr_autofocus_kernel, dim3(1), dim3(64), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.geometries, V.kd, V.kd_box, V.hot, V.hot_ids, p.W,
 		                   p.H, focal);
 		HIP_TRY(hipGetLastError());
 	}
@@ -495,7 +506,8 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 	if (s->arena.upload(d->triangles, (size_t)d->num_triangles, &d_tris)) return fail();
 
 	std::vector<HxrMeshDev> meshes((size_t)d->num_meshes);
-	std::vector<HxrKdWide> all_kd;
+	std::vector<HxrKdSlim> all_kd;
+	std::vector<HxrKdBox> all_boxes;
 	std::vector<HxrTriHot> all_hot;
 	std::vector<int32_t> all_ids;
 	for (int64_t i = 0; i < d->num_meshes; i++) {
@@ -508,7 +520,7 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		o.backface_culling = m.backface_culling;
 		o.has_kd = m.has_kd && m.num_kd_nodes > 0;
 		o.num_triangles = (int32_t)m.num_triangles;
-		int depth = append_mesh_tables(d, m, o, all_kd, all_hot, all_ids);
+		int depth = append_mesh_tables(d, m, o, all_kd, all_boxes, all_hot, all_ids);
 		if (3 * (depth + 1) > HXR_KD_STACK) {   // the packet walk queues at most three visits per level
 			set_err("kd-tree of mesh %lld is %d levels deep (limit %d)", (long long)i, depth, HXR_KD_STACK / 3 - 1);
 			return fail();
@@ -520,6 +532,7 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 	}
 	if (s->arena.upload(meshes.data(), meshes.size(), &V.meshes)) return fail();
 	if (s->arena.upload(all_kd.data(), all_kd.size(), &V.kd)) return fail();
+	if (s->arena.upload(all_boxes.data(), all_boxes.size(), &V.kd_box)) return fail();
 	if (s->arena.upload(all_hot.data(), all_hot.size(), &V.hot)) return fail();
 	if (s->arena.upload(all_ids.data(), all_ids.size(), &V.hot_ids)) return fail();
 
@@ -764,10 +777,12 @@ int hxr_get_counters(const hxr_scene* s, hxr_counters* out)
 	memset(out, 0, sizeof *out);
 	if (!s->counters_valid) { set_err("the last frame was rendered without collect_counters"); return HXR_E_INVALID; }
 	HIP_TRY(hipDeviceSynchronize());
-	unsigned long long raw[HC_NUM];
+	unsigned long long raw[HC_NUM + PH_NUM];
 	HIP_TRY(hipMemcpy(raw, s->d_counters, sizeof raw, hipMemcpyDeviceToHost));
 	uint64_t* o = (uint64_t*)out;
 	for (int i = 0; i < HC_NUM; i++) o[i] = raw[i];
+	static_assert(sizeof(hxr_counters) >= (HC_NUM + PH_NUM) * sizeof(uint64_t), "phase clocks must fit the reserved words");
+	for (int i = 0; i < PH_NUM; i++) out->reserved_[i] = raw[HC_NUM + i];   // zero unless built with -DHXR_PHASE_TIMERS
 	uint32_t flagged = 0;
 	HIP_TRY(hipMemcpy(&flagged, s->d_work + 512, sizeof flagged, hipMemcpyDeviceToHost));
 	out->aa_pixels = flagged;

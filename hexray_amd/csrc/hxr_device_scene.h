@@ -1,10 +1,12 @@
 // Device-side scene layout of the MI355X render module.
 //
 // hxr_scene_create() re-lays the flattened descriptor (include/hexray_hip.h) out for the kernels:
-//   * kd nodes become 64-byte records {box, split, first child / first triangle, axis, count}: one
-//     s_load_dwordx16.  A node's box is an exact copy of root-box bounds and split positions
-//     (BBox::split only copies values, src/bbox.h:210-216), so storing it loses nothing and frees the
-//     traversal from carrying / restoring the reference's per-level BBox copies (src/mesh.cpp:233-243);
+//   * kd nodes become 16-byte records {split, first child / first triangle, axis, count}; the two children of
+//     a node are adjacent and 32-byte aligned, so entering a node costs ONE s_load_dwordx8 for both.  A
+//     node's box is an exact copy of root-box bounds and split positions (BBox::split only copies values,
+//     src/bbox.h:210-216): on the way down the walk derives it from the parent's, and a parallel array of
+//     48-byte boxes serves the visits that resume from the stack, which frees the traversal from carrying /
+//     restoring the reference's per-level BBox copies (src/mesh.cpp:233-243);
 //   * leaf triangle lists are expanded into leaf-ordered, 96-byte "hot" records (A, AB, AC, ABxAC --
 //     exactly the operands of Mesh::intersectTriangle's rejection tests, src/mesh.cpp:178-195), so a
 //     leaf is one contiguous stream instead of index -> 184-byte Triangle gathers;
@@ -21,12 +23,17 @@
 
 #define HXR_KD_LEAF 3
 
-struct HxrKdWide {         // 64 B, 64-B aligned: one s_load_dwordx16
-	double lo[3], hi[3];   // the node's box
+struct HxrKdSlim {         // 16 B
 	double split;          // binary: splitPos
 	int32_t first;         // binary: index of the left child (right = first + 1), local to the mesh;
 	                       // leaf  : index of its first hot triangle, local to the mesh
 	int32_t axis_count;    // bits 0..1: split axis, or HXR_KD_LEAF; bits 2..: number of triangles of a leaf
+};
+
+struct HxrKdPair { HxrKdSlim kid[2]; };   // the two children of a binary node: 32 B, 32-B aligned
+
+struct HxrKdBox {          // 48 B: the box of the node with the same index
+	double lo[3], hi[3];
 };
 
 struct HxrTriHot {         // 96 B
@@ -36,7 +43,8 @@ struct HxrTriHot {         // 96 B
 struct HxrMeshDev {
 	double bbox_min[3], bbox_max[3];
 	int32_t faceted, backface_culling, has_kd, num_triangles;
-	int32_t kd_first;              // this mesh's nodes in the concatenated HxrKdWide array (node 0 of the range = root)
+	int32_t kd_first;              // this mesh's nodes in the concatenated kd arrays (node 0 of the range = root); odd, so that
+	                               // child pairs (local indices 1-2, 3-4, ...) start at even global indices
 	int32_t hot_first;             // this mesh's leaf-ordered (has_kd) or triangle-ordered (no kd) hot records / triangle ids
 	int32_t pad_[2];
 	const hxr_triangle* tris;      // cold records of this mesh
@@ -90,7 +98,8 @@ struct HxrSceneDev {
 	const hxr_layer* layers;
 	const hxr_light* lights;
 	const int32_t* env_sides;   // = &environment.side_bitmap[0] of the copy in HBM (indexed at run time; keeps this header in registers)
-	const HxrKdWide* kd;        // all meshes' kd nodes
+	const HxrKdSlim* kd;        // all meshes' kd nodes
+	const HxrKdBox* kd_box;     // their boxes
 	const HxrTriHot* hot;       // all meshes' hot triangle records
 	const int32_t* hot_ids;     // triangle number (local to its mesh) of each hot record
 };

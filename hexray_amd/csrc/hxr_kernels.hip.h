@@ -91,11 +91,28 @@ HXR_DEV f3 fdiv(f3 a, float d)                                             // Co
 HXR_DEV float intensity(f3 a) { return (a.x + a.y + a.z) / 3; }
 HXR_DEV bool is_zero(f3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 
+// Profiling builds (-DHXR_PHASE_TIMERS, tools/phase_profile.sh): every wave charges the shader-clock time between
+// two `lap(phase)` calls to the phase that just ended; the totals land in hxr_counters.reserved_[phase].
+#if !defined(HXR_PHASE_SET) || HXR_PHASE_SET == 1   // traversal in detail
+enum { PH_DISPENSE, PH_GEN, PH_QUERY, PH_MESH, PH_LEAF, PH_SHADE, PH_NUM, PH_REDUCE = PH_GEN, PH_SURFACE = PH_SHADE, PH_ENDS = PH_SHADE, PH_MAP = PH_GEN, PH_LENS = PH_GEN };
+#elif HXR_PHASE_SET == 2                            // everything around the traversal in detail
+enum { PH_DISPENSE, PH_GEN, PH_REDUCE, PH_QUERY, PH_ENDS, PH_SHADE, PH_NUM, PH_MESH = PH_QUERY, PH_LEAF = PH_QUERY, PH_SURFACE = PH_SHADE, PH_MAP = PH_GEN, PH_LENS = PH_GEN };
+#else                                               // sample generation in detail
+enum { PH_DISPENSE, PH_MAP, PH_LENS, PH_GEN, PH_REDUCE, PH_QUERY, PH_NUM, PH_MESH = PH_QUERY, PH_LEAF = PH_QUERY, PH_SURFACE = PH_QUERY, PH_ENDS = PH_QUERY, PH_SHADE = PH_QUERY };
+#endif
+
 template <bool COUNT>
 struct Tally {
 	uint32_t c[COUNT ? HC_NUM : 1];
-	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; }
 	HXR_DEV void add(int which, uint32_t n = 1) { if (COUNT) c[which] += n; }
+#ifdef HXR_PHASE_TIMERS
+	uint64_t ph[PH_NUM], t0;
+	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; for (int i = 0; i < PH_NUM; i++) ph[i] = 0; t0 = __builtin_readcyclecounter(); }
+	template <int PHASE> HXR_DEV void lap() { uint64_t now = __builtin_readcyclecounter(); ph[PHASE] += now - t0; t0 = now; }
+#else
+	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; }
+	template <int PHASE> HXR_DEV void lap() {}
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -383,6 +400,7 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
                         WaveStack& st, Tally<COUNT>& tl)
 {
 	bool found = false;
+	tl.template lap<PH_MESH>();
 	const HxrTriHot* T = S.hot + (M.hot_first + first);
 	const int32_t* ids = S.hot_ids + (M.hot_first + first);
 	if (mine) {
@@ -420,6 +438,7 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 			if (box_holds(box, o + d * gamma)) found = true;
 		}
 	}
+	tl.template lap<PH_LEAF>();
 	return found;
 }
 
@@ -446,62 +465,61 @@ template <bool COUNT>
 HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
 {
 	const unsigned long long me = 1ull << (threadIdx.x & 63);
-	const HxrKdWide* kd = S.kd + M.kd_first;
-	Box root{ld3(M.bbox_min), ld3(M.bbox_max)};
+	tl.template lap<PH_QUERY>();
+	const HxrKdSlim* kd = S.kd + M.kd_first;
+	const HxrKdBox* kd_box = S.kd_box + M.kd_first;
+	Box cb{ld3(M.bbox_min), ld3(M.bbox_max)};   // box of the current node (scalar registers); the root's is the mesh's
 	d3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
 	d3 nd = -d;
 	g.t = HXR_INF;
 	g.tri = -1;
-	bool in_root = box_test<COUNT>(root, o, d, inv, tl);
+	bool in_root = box_test<COUNT>(cb, o, d, inv, tl);
 	unsigned long long alive = __ballot(in_root);   // lanes still searching
-	if (!alive) return false;
+	if (!alive) { tl.template lap<PH_MESH>(); return false; }
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
 		leaf_query<COUNT>(S, M, 0, M.num_triangles, in_root, everything, o, d, nd, g, st, tl);
+		tl.template lap<PH_MESH>();
 		return in_root && g.t < HXR_INF;
 	}
 	bool found = false;
 	int sp = 0;
 	unsigned long long mask = alive;   // lanes taking part in the visit of the current node
 	if (in_root) tl.add(HC_KD);
-	HxrKdWide R = kd[0];               // record of the current node (scalar registers)
+	HxrKdSlim R = kd[0];               // record of the current node (scalar registers)
 	for (;;) {
 		const int ac = R.axis_count;
 		const int axis = ac & 3;
-		// `next` / `next_mask`: a visit to try right away (its box is derived from R, no load needed); otherwise pop
-		int next = -1;
-		unsigned long long next_mask = 0;
-		Box nb{ld3(R.lo), ld3(R.hi)};
-		HxrKdWide kid0, kid1;
+		bool descended = false;
 		if (axis == HXR_KD_LEAF) {
-			bool here = leaf_query<COUNT>(S, M, R.first, ac >> 2, (mask & me) != 0, nb, o, d, nd, g, st, tl);
+			bool here = leaf_query<COUNT>(S, M, R.first, ac >> 2, (mask & me) != 0, cb, o, d, nd, g, st, tl);
 			found = found || here;
 			alive &= ~__ballot(here);
 		} else {
 			const double split = R.split;
 			const int left = R.first;
-			kid0 = kd[left];           // in flight while the first child's box is being tested
-			kid1 = kd[left + 1];
+			const HxrKdPair kids = *(const HxrKdPair*)(kd + left);   // in flight while the first child's box is being tested
 			bool right_first = (mask & me) && comp(o, axis) > split;
 			unsigned long long rm = __ballot(right_first), lm = mask & ~rm;
-			// the visits of this node's children, in execution order: first one directly, the others through the stack
+			// the visits of this node's children, in execution order: the first one directly (its box derives from
+			// this node's, no load needed), the others through the stack
+			const bool go_left = lm != 0;
+			const unsigned long long next_mask = go_left ? lm : rm;
 			if (lm && rm) {
 				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
 				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)mask; st.mask_hi[sp] = (uint32_t)(mask >> 32); sp++;
-				next = left; next_mask = lm;
-			} else if (lm) {
-				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)lm; st.mask_hi[sp] = (uint32_t)(lm >> 32); sp++;
-				next = left; next_mask = lm;
 			} else {
-				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
-				next = left + 1; next_mask = rm;
+				st.node[sp] = go_left ? left + 1 : left; st.mask_lo[sp] = (uint32_t)next_mask; st.mask_hi[sp] = (uint32_t)(next_mask >> 32); sp++;
 			}
 			// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
-			if (next == left) { if (axis == 0) nb.hi.x = split; else if (axis == 1) nb.hi.y = split; else nb.hi.z = split; }
-			else { if (axis == 0) nb.lo.x = split; else if (axis == 1) nb.lo.y = split; else nb.lo.z = split; }
-		}
-		bool descended = false;
-		if (next >= 0) {   // first child of the node just entered: nobody has found anything since `mask` was formed
+			Box nb;
+			nb.lo.x = (!go_left && axis == 0) ? split : cb.lo.x;
+			nb.lo.y = (!go_left && axis == 1) ? split : cb.lo.y;
+			nb.lo.z = (!go_left && axis == 2) ? split : cb.lo.z;
+			nb.hi.x = (go_left && axis == 0) ? split : cb.hi.x;
+			nb.hi.y = (go_left && axis == 1) ? split : cb.hi.y;
+			nb.hi.z = (go_left && axis == 2) ? split : cb.hi.z;
+			// first child of the node just entered: nobody has found anything since `mask` was formed
 			bool pass = false;
 			if (next_mask & me) {
 				pass = box_test<COUNT>(nb, o, d, inv, tl);
@@ -509,7 +527,8 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			}
 			unsigned long long m2 = __ballot(pass);
 			if (m2) {
-				R = (next == R.first) ? kid0 : kid1;
+				R = go_left ? kids.kid[0] : kids.kid[1];
+				cb = nb;
 				mask = m2;
 				descended = true;
 			}
@@ -521,22 +540,25 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.mask_lo[sp]);
 			unsigned long long m = pm & alive;
 			if (!m) continue;
-			HxrKdWide C = kd[cn];
+			HxrKdSlim C = kd[cn];
+			HxrKdBox CB = kd_box[cn];
+			Box pb{ld3(CB.lo), ld3(CB.hi)};
 			bool pass = false;
 			if (m & me) {
-				Box cb{ld3(C.lo), ld3(C.hi)};
-				pass = box_test<COUNT>(cb, o, d, inv, tl);
+				pass = box_test<COUNT>(pb, o, d, inv, tl);
 				if (pass) tl.add(HC_KD);
 			}
 			unsigned long long m2 = __ballot(pass);
 			if (m2) {
 				R = C;
+				cb = pb;
 				mask = m2;
 				descended = true;
 			}
 		}
 		if (!descended) break;
 	}
+	tl.template lap<PH_MESH>();
 	return found;
 }
 
@@ -1127,7 +1149,9 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 		// ---- 2. the one traversal site
 		GeomHit bg;
 		double bw;
+		tl.template lap<PH_SHADE>();
 		int node = scene_query<COUNT, F>(S, qo, qd, qlimit, qany, bg, bw, st, tl);
+		tl.template lap<PH_QUERY>();
 
 		// ---- 3. consume the answer
 		bool run_shaders = false;   // Whitted: continue with the shader work list of the current hit
@@ -1214,6 +1238,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 			}
 		}
 
+		tl.template lap<PH_ENDS>();
 		if (gi && path_vertex) {
 			// ---- path tracing: one vertex = [light sample] then spawn (src/main.cpp:122-168)
 			Surface sfl;   // texture_sample() reads u, v, norm
@@ -1425,10 +1450,14 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 			if (!(lu * lu + lv * lv > 1)) break;
 		}
 	}
+	tl.template lap<PH_LENS>();
 	d3 o, d;
 	if (S.camera.stereo_separation == 0.0) {
 		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
-		return trace_rays<COUNT, F>(S, o, d, rc, st, tl);
+		tl.template lap<PH_GEN>();
+		f3 c = trace_rays<COUNT, F>(S, o, d, rc, st, tl);
+		tl.template lap<PH_SHADE>();
+		return c;
 	}
 	f3 eye[2];
 	for (int e = 0; e < 2; e++) {   // anaglyph pair (src/main.cpp:237-247)
@@ -1445,6 +1474,12 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 // Pixels of a shard are numbered tile by tile; inside a tile in 8x8 blocks (row-major), inside a block
 // along a Morton curve, so every aligned group of 4 / 16 / 64 consecutive pixels is a 2x2 / 4x4 / 8x8
 // square of the image: the lanes of a wave stay spatially coherent for every power-of-two spp.
+// value of the lane below (lane 0 keeps 0): DPP wave_shr:1
+HXR_DEV float wave_shr1(float v)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+
 HXR_DEV void morton6(uint32_t m, int& x, int& y)
 {
 	x = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
@@ -1498,7 +1533,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
     const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
     const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights,
-    const HxrKdWide* __restrict__ a_kd, const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids,
+    const HxrKdSlim* __restrict__ a_kd, const HxrKdBox* __restrict__ a_kd_box, const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids,
     const hxr_geometry* __restrict__ a_geoms, HxrLaunch P)
 {
 	// The small tables arrive as separate `const __restrict__` kernel arguments: only then can the compiler
@@ -1514,10 +1549,10 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 	S.layers = a_layers;
 	S.lights = a_lights;
 	S.kd = a_kd;
+	S.kd_box = a_kd_box;
 	S.hot = a_hot;
 	S.hot_ids = a_hot_ids;
 	S.geometries = a_geoms;
-	__shared__ float lds_rgb[HXR_BLOCK / 64][64][3];
 	__shared__ WaveStack lds_stack[HXR_BLOCK / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	Tally<COUNT> tl;
@@ -1554,6 +1589,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 			}
 			if (!got) break;
 		}
+		tl.template lap<PH_DISPENSE>();
 		const uint32_t chunk = batch_pos++;
 		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
 		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
@@ -1575,6 +1611,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 				if (live) { int pix = P.extra_pixels[e]; x = pix % P.W; y = pix / P.W; }
 			}
 		}
+		tl.template lap<PH_MAP>();
 		f3 sum = mkf(0, 0, 0);
 		if (live) {
 			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
@@ -1598,30 +1635,34 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 				sum = (rd == 0) ? c : sum + c;
 			}
 		}
-		// combine the samples of each pixel in sample order (the reference adds them one by one, src/main.cpp:372-377)
-		lds_rgb[wave][lane][0] = sum.x;
-		lds_rgb[wave][lane][1] = sum.y;
-		lds_rgb[wave][lane][2] = sum.z;
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		if (live && sub == 0) {
-			const bool in_tile = P.mode != 2 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
-			float* dst = in_tile ? out_pixel(P, q, x, y) : (float*)((char*)P.out + (size_t)y * P.out_stride) + (size_t)x * 3;
-			f3 t = (P.mode == 2) ? mkf(dst[0], dst[1], dst[2]) : mkf(0, 0, 0);   // pass 3 adds onto the pass-1 colour
-			for (int i = 0; i < lanes_per_pixel; i++) {
-				const float* s = lds_rgb[wave][lane + i];
-				t = mkf(t.x + s[0], t.y + s[1], t.z + s[2]);
-			}
-			if (P.mode == 1) t = t * (1.0f / spp);
-			else if (P.mode == 2) t = t * (1.0f / 5);
-			dst[0] = t.x;
-			dst[1] = t.y;
-			dst[2] = t.z;
+		// Combine the samples of each pixel in sample order (the reference adds them one by one, src/main.cpp:372-377).
+		// The lanes of a pixel are adjacent, so the running sum walks through them with one wave-shift per sample:
+		// after step k the lane of sample k holds ((s0 + s1) + ...) + sk.  No LDS round trip, all lanes in lockstep.
+		const bool in_tile = P.mode != 2 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+		float* dst = nullptr;
+		f3 acc = mkf(0, 0, 0);
+		if (live && (sub == 0 || sub == lanes_per_pixel - 1)) {
+			dst = in_tile ? out_pixel(P, q, x, y) : (float*)((char*)P.out + (size_t)y * P.out_stride) + (size_t)x * 3;
+			if (P.mode == 2 && sub == 0) acc = mkf(dst[0], dst[1], dst[2]);   // pass 3 adds onto the pass-1 colour
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+		acc = acc + sum;
+		for (int k = 1; k < lanes_per_pixel; k++) {
+			f3 left = mkf(wave_shr1(acc.x), wave_shr1(acc.y), wave_shr1(acc.z));
+			if (sub == k) acc = left + sum;
+		}
+		if (live && sub == lanes_per_pixel - 1) {
+			if (P.mode == 1) acc = acc * (1.0f / spp);
+			else if (P.mode == 2) acc = acc * (1.0f / 5);
+			dst[0] = acc.x;
+			dst[1] = acc.y;
+			dst[2] = acc.z;
+		}
+		tl.template lap<PH_REDUCE>();
 	}
+#ifdef HXR_PHASE_TIMERS
+	if (P.counters && lane == 0)
+		for (int i = 0; i < PH_NUM; i++) atomicAdd(&P.counters[HC_NUM + i], (unsigned long long)tl.ph[i]);
+#endif
 	if (COUNT && P.counters) {
 		for (int i = 0; i < HC_NUM; i++) {
 			uint32_t v = tl.c[i];
@@ -1635,7 +1676,7 @@ __global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
 // ray through the frame centre becomes the focal plane distance.  One wavefront, every lane the same ray.
 __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
-    const HxrHeightfieldDev* __restrict__ a_hfs, const hxr_geometry* __restrict__ a_geoms, const HxrKdWide* __restrict__ a_kd,
+    const HxrHeightfieldDev* __restrict__ a_hfs, const hxr_geometry* __restrict__ a_geoms, const HxrKdSlim* __restrict__ a_kd, const HxrKdBox* __restrict__ a_kd_box,
     const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids, int W, int H, double* focal_out)
 {
 	__shared__ WaveStack st;
@@ -1645,6 +1686,7 @@ __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
 	S.heightfields = a_hfs;
 	S.geometries = a_geoms;
 	S.kd = a_kd;
+	S.kd_box = a_kd_box;
 	S.hot = a_hot;
 	S.hot_ids = a_hot_ids;
 	Tally<false> tl;
