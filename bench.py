@@ -36,6 +36,9 @@ WORKLOADS = {
                       "data/heightfield.hexray 1920x1080 x 16 spp (Camera dof on, numSamples 16)"),
     "smallpt256": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=256), "data/smallpt.hexray 1920x1080 x 256 paths"),
     "smallpt16": ("smallpt.hexray", dict(width=1920, height=1080, num_paths=16), "data/smallpt.hexray 1920x1080 x 16 paths"),
+    # the two catch-all kernel variants (every geometry kind compiled in; with / without path tracing)
+    "cornell16": ("cornell_box.hexray", dict(width=1920, height=1080, num_paths=16), "data/cornell_box.hexray 1920x1080 x 16 paths (GI over meshes)"),
+    "kdtree16": ("kdtree_test.hexray", dict(width=1920, height=1080, dof=True, num_samples=16), "data/kdtree_test.hexray 1920x1080 x 16 spp (CSG + kd mesh)"),
     # no nodes at all: the fixed per-packet cost (sample generation, camera, reduction, store)
     "empty16": ("../tests/golden/tiny.hexray", dict(width=1920, height=1080, dof=True, num_samples=16), "empty scene 1920x1080 x 16 spp (overhead probe)"),
 }

@@ -304,21 +304,24 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 	if (L.num_chunks > 0) {
 		int grid = grid_for(L.num_chunks);
 		const HxrSceneDev& V = s->host_view;
-#define HXR_LAUNCH(CNT, FEAT)                                                                                                                   \
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, \
+#define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                     \
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, \
 	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L)
-#define HXR_LAUNCH_F(FEAT)                                                  \
-	do {                                                                    \
-		if (counters) HXR_LAUNCH(true, FEAT); else HXR_LAUNCH(false, FEAT); \
+#define HXR_LAUNCH_F(FEAT, WAVES)                                                         \
+	do {                                                                                  \
+		if (counters) HXR_LAUNCH(true, FEAT, WAVES); else HXR_LAUNCH(false, FEAT, WAVES); \
 	} while (0)
-		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h)
+		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h);
+		// occupancy target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel)
 		const unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
-		const bool gi = s->settings.gi != 0;
-		if (!gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH);
-		else if (!gi && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD);
-		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI);
-		else if (gi) HXR_LAUNCH_F(HXR_F_ALL);
-		else HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI);
+		const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
+		if (!gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
+		else if (!gi && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD, 2);
+		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI, 2);
+		else if (gi && meshes) HXR_LAUNCH_F(HXR_F_ALL, 3);
+		else if (gi) HXR_LAUNCH_F(HXR_F_ALL, 2);
+		else if (meshes) HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3);
+		else HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 2);
 #undef HXR_LAUNCH_F
 #undef HXR_LAUNCH
 		HIP_TRY(hipGetLastError());

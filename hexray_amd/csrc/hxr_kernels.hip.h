@@ -1524,12 +1524,13 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 #ifndef HXR_BATCH
 #define HXR_BATCH 1           // packets per ticket (larger batches unbalance the waves: expensive packets are spatially clustered)
 #endif
-#ifndef HXR_MIN_WAVES
-#define HXR_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for
-#endif
-
-template <bool COUNT, unsigned F>
-__global__ __launch_bounds__(HXR_BLOCK, HXR_MIN_WAVES) void hxr_render_kernel(
+// Waves per SIMD the register allocator must leave room for (template parameter W of the kernel; measured on
+// MI355X): kernels that walk kd-trees are fastest at 3 (168 VGPRs, ~220 spilled: the packet walk
+// needs the latency hiding more than the registers) -- mesh-only Whitted, and the catch-all variants on scenes
+// with meshes (12 % faster than at 2); the heightfield marcher and the sphere path tracer keep more per-lane
+// state alive and are 16 % / 21 % faster at 2 (256 VGPRs, almost nothing spilled).
+template <bool COUNT, unsigned F, int W>
+__global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
     const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
     const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights,
