@@ -154,6 +154,20 @@ int validate(const hxr_scene_desc* d)
 	return 0;
 }
 
+// does anything reachable from this shader read a texture (and with it IntersectionInfo::u / v)?
+bool shader_reads_textures(const hxr_scene_desc* d, int shader, int depth)
+{
+	if (shader < 0 || shader >= d->num_shaders || depth > 16) return true;   // be conservative about what validate() did not follow
+	const hxr_shader& sh = d->shaders[shader];
+	if (sh.texture >= 0) return true;
+	if (sh.type == HXR_SHADER_LAYERED)
+		for (int i = 0; i < sh.num_layers; i++) {
+			const hxr_layer& L = d->layers[sh.first_layer + i];
+			if (L.texture >= 0 || shader_reads_textures(d, L.shader, depth + 1)) return true;
+		}
+	return false;
+}
+
 // Slim kd records + node boxes + leaf-ordered hot triangles of one mesh, appended to the scene-wide arrays
 // (see hxr_device_scene.h)
 int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdSlim>& kd, std::vector<HxrKdBox>& boxes,
@@ -579,6 +593,7 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		o.ref = g.ref;
 		o.shader = n.shader;
 		o.bump = n.bump;
+		o.needs_uv = (n.bump >= 0 || shader_reads_textures(d, n.shader, 0)) ? 1 : 0;
 		memcpy(o.p, g.p, sizeof o.p);
 		// object-space bounds of the geometry, if it has finite ones
 		double lo[3], hi[3];

@@ -749,12 +749,14 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 			break;
 		case HXR_GEOM_SPHERE: if constexpr ((F & HXR_F_SPHERE) != 0) {
 			n = unit(ip - ld3(N.p));
-			double v = asin(n.y), u = atan2(n.z, n.x);
-			v = -(v / HXR_PI + 0.5f);
-			u = u / (2 * HXR_PI) + 0.5f;
-			if (N.p[4] != 1) { u *= N.p[4]; v *= N.p[4]; }
-			sf.u = u;
-			sf.v = v;
+			if (N.needs_uv) {   // asin / atan2 in FP64 cost more than the rest of the hit: only when a texture or bump map will read them
+				double v = asin(n.y), u = atan2(n.z, n.x);
+				v = -(v / HXR_PI + 0.5f);
+				u = u / (2 * HXR_PI) + 0.5f;
+				if (N.p[4] != 1) { u *= N.p[4]; v *= N.p[4]; }
+				sf.u = u;
+				sf.v = v;
+			}
 			break;
 		}
 		case HXR_GEOM_CUBE: if constexpr ((F & HXR_F_CUBE) != 0) {
@@ -1057,18 +1059,22 @@ struct HitPoint {
 // those indices would pull whole records -- a 240-byte Transform per node or light -- into vector registers
 // of every lane.  Instead each distinct index present in the wave is handled in turn ("waterfall":
 // readfirstlane picks an index, the lanes that hold it run the body with a wave-uniform index, the record
-// arrives through scalar loads); a wave holds one to three distinct values in practice.
+// arrives through scalar loads); a wave of a Whitted frame holds one to three distinct values in practice.
+// The rays of a path tracer scatter after the first bounce -- a wave then holds nearly every node and shader of
+// the scene and the waterfall would run its body once per value -- so the GI variants read the records with
+// per-lane indices instead (`gather_records`): one pass, vector loads from tables that sit in L1.
 enum { Q_NONE = 0, Q_CLOSEST = 1, Q_SHADOW = 2 };
 
 #define HXR_WATERFALL(var, uni)                                                        \
 	for (bool wf_done_ = false; !wf_done_;)                                            \
-		for (const int uni = __builtin_amdgcn_readfirstlane(var); !wf_done_ && (var) == uni; wf_done_ = true)
+		for (const int uni = gather_records ? (var) : __builtin_amdgcn_readfirstlane(var); !wf_done_ && (var) == uni; wf_done_ = true)
 
 template <bool COUNT, unsigned F>
 HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
 {
 	constexpr bool gi = (F & HXR_F_GI) != 0;   // the launcher picks the variant that matches settings.gi
 	constexpr bool glossy = (F & HXR_F_EXTRA) != 0;
+	constexpr bool gather_records = gi;
 	StackItem<glossy> stack[HXR_RAY_STACK];
 	int sh_stack[HXR_SHADER_STACK];
 	f3 w_stack[HXR_SHADER_STACK];
