@@ -407,35 +407,37 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 		for (int i = 0; i < count; i++) {
 			tl.add(HC_TRI);
 			tl.add(HC_LEAFIDX);
+			bool ok = true;
 			if (M.backface_culling) {
 				const hxr_triangle& ct = M.tris[ids[i]];
-				if (dot(d, ld3(ct.gnormal)) > 0) continue;
+				ok = !(dot(d, ld3(ct.gnormal)) > 0);
 			}
+			// The four sign / magnitude rejections are evaluated without branching between them: the lanes of a
+			// packet fail at different ones, so nested early-outs only add mask bookkeeping (8 levels of it).
 			d3 N = ld3(T[i].N);
 			double Dcr = dot(N, nd);
-			if (fabs(Dcr) < 1e-12) continue;
 			d3 H = o - ld3(T[i].A);
 			bool neg = Dcr < 0;
 			double ga = dot(N, H);
-			if ((ga < 0) != neg && ga != 0) continue;          // gamma < 0
 			double gb = dot(cross(H, ld3(T[i].AC)), nd);
-			if ((gb < 0) != neg && gb != 0) continue;          // lambda2 < 0
 			double gc = dot(cross(ld3(T[i].AB), H), nd);
-			if ((gc < 0) != neg && gc != 0) continue;          // lambda3 < 0
-			double rD = 1 / Dcr;
-			double gamma = ga * rD;
-			if (gamma < 0 || gamma > g.t) continue;
-			double l2 = gb * rD;
-			if (l2 < 0 || l2 > 1) continue;
-			double l3 = gc * rD;
-			if (l3 < 0 || l3 > 1) continue;
-			double l1 = 1 - (l2 + l3);
-			if (l1 < 0 || l1 > 1) continue;
-			g.t = gamma;
-			g.l2 = l2;
-			g.l3 = l3;
-			g.tri = ids[i];
-			if (box_holds(box, o + d * gamma)) found = true;
+			ok = ok & !(fabs(Dcr) < 1e-12)
+			        & !(((ga < 0) != neg) & (ga != 0))    // gamma < 0
+			        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
+			        & !(((gc < 0) != neg) & (gc != 0));   // lambda3 < 0
+			if (ok) {
+				double rD = 1 / Dcr;
+				double gamma = ga * rD, l2 = gb * rD, l3 = gc * rD;
+				double l1 = 1 - (l2 + l3);
+				bool take = !(gamma < 0 || gamma > g.t) & !(l2 < 0 || l2 > 1) & !(l3 < 0 || l3 > 1) & !(l1 < 0 || l1 > 1);
+				if (take) {
+					g.t = gamma;
+					g.l2 = l2;
+					g.l3 = l3;
+					g.tri = ids[i];
+					if (box_holds(box, o + d * gamma)) found = true;
+				}
+			}
 		}
 	}
 	tl.template lap<PH_LEAF>();
