@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="meshes16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accel", default="reference", choices=["reference", "sah"],
+                    help="kd-trees walked by the timed frames: the reference's own (default) or the module's SAH rebuild")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,10 +89,15 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     scene_name, ov, description = WORKLOADS[args.workload]
-    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+    t_prep = time.perf_counter()
+    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))   # parse + prepareTriangles + reference kd build + flatten
+    host_prep_s = time.perf_counter() - t_prep
     hx.init(local_rank)
     torch.cuda.set_device(local_rank)
-    ds = hx.DeviceScene(hs)
+    accel = hx.ACCEL_SAH if args.accel == "sah" else hx.ACCEL_REFERENCE
+    t_prep = time.perf_counter()
+    ds = hx.DeviceScene(hs, accel=accel)
+    device_prep_s = time.perf_counter() - t_prep
     W, H = hs.settings.frame_width, hs.settings.frame_height
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -188,6 +195,7 @@ def main():
             "dtype": "f64",
             "data": "scene asset data/%s shipped with the reference (no external dataset)" % scene_name,
             "config": {"workload": description, "width": W, "height": H, "spp": spp if spp > 0 else 1, "tile_size": TILE,
+                       "accel": "reference kd-tree (as handed over by the host)" if accel == hx.ACCEL_REFERENCE else "SAH kd-tree rebuilt by the module",
                        "parallelism": "tile-shard x%d, one RCCL gather" % world if world > 1 else "single GPU", "rng_seed": int(probe.rng_seed)},
         }
         if counters is not None:
@@ -211,6 +219,27 @@ def main():
         else:
             result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                   "kernel_ms": round(kernel_ms_mean, 4), "note": "per-rank kernel time of rank 0; counters are collected at N=1 only"}
+        # outside the timed region, reported separately: scene preparation
+        result["scene_prep_s"] = {"host_parse_kd_build_flatten": round(host_prep_s, 3), "hxr_scene_create": round(device_prep_s, 3)}
+        if world == 1 and accel == hx.ACCEL_REFERENCE:
+            # SURVEY.md 8(f) rank 1, measured beside the headline: the same frame through the module's SAH kd-trees
+            ref_frame = frame.clone()
+            alt = hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
+            alt_ms = []
+            for i in range(2 + min(args.steps, 10)):
+                alt.render_device(params, frame.data_ptr(), W * 12, stream)
+                torch.cuda.synchronize()
+                if i >= 2:
+                    alt_ms.append(alt.last_kernel_ms())
+            diff = (frame - ref_frame).abs()
+            alt.render_device(cparams, frame.data_ptr(), W * 12, stream)
+            torch.cuda.synchronize()
+            ac = alt.counters()
+            result["sah_tree"] = {"kernel_ms": round(float(np.mean(alt_ms)), 4), "Msamples_per_s_kernel": round(samples_per_frame / (float(np.mean(alt_ms)) * 1e-3) / 1e6, 1),
+                                  "reference_tree_kernel_ms": round(kernel_ms_mean, 4),
+                                  "max_abs_diff_vs_reference_tree_frame": float(diff.max().item()), "pixels_differing": int((diff.amax(dim=2) > 0).sum().item()),
+                                  "tri_tests_per_sample": round(ac["tri_tests"] / ac["camera_samples"], 2), "kd_visits_per_sample": round(ac["kd_visits"] / ac["camera_samples"], 2)}
+            del alt
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene_name, ov, samples_per_frame)
     if world > 1:

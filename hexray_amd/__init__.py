@@ -45,6 +45,15 @@ COUNTER_FIELDS = [
 ]
 
 
+ACCEL_REFERENCE, ACCEL_SAH = 0, 1
+
+
+class SceneOptions(ctypes.Structure):
+    """hxr_scene_options (include/hexray_hip.h)."""
+
+    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32)]
+
+
 class Counters(ctypes.Structure):
     """hxr_counters (include/hexray_hip.h)."""
 
@@ -227,6 +236,9 @@ def hip_lib():
         lib.hxr_init.argtypes = [c_int]
         lib.hxr_scene_create.restype = c_void_p
         lib.hxr_scene_create.argtypes = [c_void_p]
+        lib.hxr_scene_create_ex.restype = c_void_p
+        lib.hxr_scene_create_ex.argtypes = [c_void_p, POINTER(SceneOptions)]
+        lib.hxr_scene_tree_stats.argtypes = [c_void_p, c_int, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(c_int)]
         lib.hxr_scene_update_camera.argtypes = [c_void_p, c_void_p]
         lib.hxr_render.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
         lib.hxr_render_device.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p]
@@ -269,15 +281,26 @@ def init(device_id: int = 0):
 
 
 class DeviceScene:
-    """A scene resident in HBM (hxr_scene)."""
+    """A scene resident in HBM (hxr_scene).  ``accel``: ACCEL_REFERENCE walks the kd-trees of the descriptor (the
+    reference's own), ACCEL_SAH rebuilds them with the surface-area heuristic (hxr_scene_create_ex)."""
 
-    def __init__(self, host_scene: HostScene):
+    def __init__(self, host_scene: HostScene, accel: int = 0):
         if _initialised_device is None:
             init(0)
-        self._s = hip_lib().hxr_scene_create(host_scene.desc)
+        if accel == ACCEL_REFERENCE:
+            self._s = hip_lib().hxr_scene_create(host_scene.desc)
+        else:
+            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel)
+            self._s = hip_lib().hxr_scene_create_ex(host_scene.desc, ctypes.byref(opt))
         if not self._s:
             raise HipError("hxr_scene_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))
         self.host = host_scene
+
+    def tree_stats(self, mesh: int):
+        """(nodes, leaf entries, max depth) of the tree walked for mesh ``mesh``."""
+        n, l, dpt = ctypes.c_int64(), ctypes.c_int64(), c_int()
+        _check(hip_lib().hxr_scene_tree_stats(self._s, mesh, ctypes.byref(n), ctypes.byref(l), ctypes.byref(dpt)), "hxr_scene_tree_stats")
+        return n.value, l.value, dpt.value
 
     def update_camera(self):
         cam_addr = ctypes.addressof(SceneDescHeader.from_address(self.host.desc).camera)

@@ -13,6 +13,7 @@
 #include <vector>
 #include "hexray_hip.h"
 #include "hxr_kernels.hip.h"
+#include "hxr_accel.h"
 
 namespace {
 
@@ -73,6 +74,8 @@ struct hxr_scene {
 	hxr_settings settings;
 	hxr_camera camera;
 	unsigned features = 0;          // HXR_F_* geometry kinds present among the nodes
+	struct TreeStats { int64_t nodes, leaf_entries; int depth; };
+	std::vector<TreeStats> tree_stats;   // per mesh: the tree actually walked
 	// per-frame scratch, grown on demand
 	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
 	float* d_scratch = nullptr;     size_t scratch_bytes = 0;  // sharded-AA full frame
@@ -170,12 +173,11 @@ bool shader_reads_textures(const hxr_scene_desc* d, int shader, int depth)
 
 // Slim kd records + node boxes + leaf-ordered hot triangles of one mesh, appended to the scene-wide arrays
 // (see hxr_device_scene.h)
-int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o, std::vector<HxrKdSlim>& kd, std::vector<HxrKdBox>& boxes,
-                       std::vector<HxrTriHot>& hot, std::vector<int32_t>& ids)
+// `nodes` / `num_nodes` / `leaf_idx`: the tree to lay out (the descriptor's, or an HXR_ACCEL_SAH rebuild)
+int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, const hxr_kd_node* nodes, int64_t num_nodes, const int32_t* leaf_idx, HxrMeshDev& o,
+                       std::vector<HxrKdSlim>& kd, std::vector<HxrKdBox>& boxes, std::vector<HxrTriHot>& hot, std::vector<int32_t>& ids)
 {
 	int max_depth = 0;
-	const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
-	const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
 	const hxr_triangle* tris = d->triangles + m.first_triangle;
 	const double* verts = d->f64_pool + m.first_vertex * 3;
 	if (kd.size() % 2 == 0) {   // roots sit at odd global indices: every child pair is then 32-byte aligned
@@ -197,13 +199,13 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, HxrMeshDev& o
 		hot.push_back(h);
 		ids.push_back(ti);
 	};
-	if (!m.has_kd || m.num_kd_nodes == 0) {
+	if (!m.has_kd || num_nodes == 0) {
 		for (int64_t i = 0; i < m.num_triangles; i++) push_hot((int)i);
 		return 0;
 	}
 	const size_t kd0 = kd.size();
-	kd.resize(kd0 + (size_t)m.num_kd_nodes);
-	boxes.resize(kd0 + (size_t)m.num_kd_nodes);
+	kd.resize(kd0 + (size_t)num_nodes);
+	boxes.resize(kd0 + (size_t)num_nodes);
 	struct Item { int node; int depth; double lo[3], hi[3]; };
 	std::vector<Item> todo;
 	Item root;
@@ -499,10 +501,18 @@ int hxr_init(int device_id)
 	return 0;
 }
 
-hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
+hxr_scene* hxr_scene_create(const hxr_scene_desc* d) { return hxr_scene_create_ex(d, nullptr); }
+
+hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options* opt)
 {
 	if (g_device < 0) { set_err("hxr_init has not been called"); return nullptr; }
 	if (validate(d)) return nullptr;
+	int accel = HXR_ACCEL_REFERENCE;
+	if (opt) {
+		if (opt->struct_size < sizeof(hxr_scene_options)) { set_err("hxr_scene_options.struct_size too small"); return nullptr; }
+		accel = opt->accel;
+		if (accel != HXR_ACCEL_REFERENCE && accel != HXR_ACCEL_SAH) { set_err("unknown acceleration structure %d", accel); return nullptr; }
+	}
 	hxr_scene* s = new hxr_scene;
 	auto fail = [&]() -> hxr_scene* { hxr_scene_destroy(s); return nullptr; };
 	HxrSceneDev& V = s->host_view;
@@ -537,7 +547,23 @@ hxr_scene* hxr_scene_create(const hxr_scene_desc* d)
 		o.backface_culling = m.backface_culling;
 		o.has_kd = m.has_kd && m.num_kd_nodes > 0;
 		o.num_triangles = (int32_t)m.num_triangles;
-		int depth = append_mesh_tables(d, m, o, all_kd, all_boxes, all_hot, all_ids);
+		const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
+		const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
+		int64_t num_nodes = m.num_kd_nodes, num_leaf_entries = m.num_leaf_indices;
+		hxr_sah::SahTree sah;
+		if (accel == HXR_ACCEL_SAH && o.has_kd) {   // meshes the caller wants brute-forced (useKDTree off) stay that way
+			hxr_sah::SahParams sp;
+			if (const char* e = getenv("HXR_SAH_TRAVERSAL_COST")) sp.traversal_cost = atof(e);   // developer aids for tuning the cost model
+			if (const char* e = getenv("HXR_SAH_EMPTY_BONUS")) sp.empty_bonus = atof(e);
+			if (const char* e = getenv("HXR_SAH_MIN_LEAF")) sp.min_leaf = atoi(e);
+			hxr_sah::SahBuilder(d->triangles + m.first_triangle, m.num_triangles, d->f64_pool + m.first_vertex * 3, sp).build(m.bbox_min, m.bbox_max, sah);
+			nodes = sah.nodes.data();
+			leaf_idx = sah.leaf_indices.data();
+			num_nodes = (int64_t)sah.nodes.size();
+			num_leaf_entries = (int64_t)sah.leaf_indices.size();
+		}
+		int depth = append_mesh_tables(d, m, nodes, num_nodes, leaf_idx, o, all_kd, all_boxes, all_hot, all_ids);
+		s->tree_stats.push_back({num_nodes, num_leaf_entries, depth});
 		if (3 * (depth + 1) > HXR_KD_STACK) {   // the packet walk queues at most three visits per level
 			set_err("kd-tree of mesh %lld is %d levels deep (limit %d)", (long long)i, depth, HXR_KD_STACK / 3 - 1);
 			return fail();
@@ -786,6 +812,15 @@ int hxr_quantize_srgb8(const float* d_frame, size_t row_stride_bytes, int width,
 	hipLaunchKernelGGL(hxr_quantize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_frame, row_stride_bytes, width, height,
 	                   (const uint8_t*)lut, d_bgr);
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int hxr_scene_tree_stats(const hxr_scene* s, int mesh, int64_t* nodes, int64_t* leaf_entries, int* max_depth)
+{
+	if (!s || mesh < 0 || (size_t)mesh >= s->tree_stats.size()) { set_err("no such mesh"); return HXR_E_INVALID; }
+	if (nodes) *nodes = s->tree_stats[(size_t)mesh].nodes;
+	if (leaf_entries) *leaf_entries = s->tree_stats[(size_t)mesh].leaf_entries;
+	if (max_depth) *max_depth = s->tree_stats[(size_t)mesh].depth;
 	return 0;
 }
 

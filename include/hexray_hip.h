@@ -308,6 +308,26 @@ int hxr_init(int device_id);
  * Returns NULL on failure; hxr_last_error() says why. */
 hxr_scene* hxr_scene_create(const hxr_scene_desc* desc);
 
+/* Acceleration structure walked by Mesh::intersect's replacement. */
+enum hxr_accel {
+	HXR_ACCEL_REFERENCE = 0,  /* the kd-tree in the descriptor, i.e. the reference's own (Mesh::buildKD, src/mesh.cpp:86-122) */
+	HXR_ACCEL_SAH = 1         /* kd-trees rebuilt per mesh with the surface-area heuristic ("a better
+	                             tree proven <= 1e-4 against the reference-identical one"); same walk, same leaf rule, same
+	                             triangle test -- ties between triangles hit at bit-equal distance may resolve differently */
+};
+
+typedef struct hxr_scene_options {
+	uint32_t struct_size;     /* sizeof(hxr_scene_options): lets the record grow */
+	int32_t accel;            /* enum hxr_accel */
+} hxr_scene_options;
+
+/* hxr_scene_create with options (NULL = defaults = hxr_scene_create). */
+hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* desc, const hxr_scene_options* options);
+
+/* Nodes / leaf entries / depth of the tree actually walked for mesh `mesh` (after an HXR_ACCEL_SAH rebuild these
+ * differ from the descriptor's).  The reference prints the same statistics at load (src/mesh.cpp:39-47). */
+int hxr_scene_tree_stats(const hxr_scene* scene, int mesh, int64_t* nodes, int64_t* leaf_entries, int* max_depth);
+
 /* Per-frame camera update (Camera::beginFrame, src/camera.cpp:30-63, after move/rotate). */
 int hxr_scene_update_camera(hxr_scene* scene, const hxr_camera* camera);
 

@@ -220,3 +220,49 @@ def test_headline_scene_full_size_against_oracle_strip(gpu):
     for k in EXACT_COUNTERS:
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the surface-area-heuristic kd-tree must give the image of the reference's tree
+# ---------------------------------------------------------------------------------------------------
+SAH_SCENES = [
+    ("meshes.hexray", hx.overlay_text(320, 180, want_aa=False), dict(mode=hx.MODE_SINGLE)),
+    ("meshes.hexray", hx.overlay_text(240, 136), dict(mode=hx.MODE_ADAPTIVE_AA)),
+    ("meshes.hexray", hx.overlay_text(200, 112, dof=True, num_samples=8), dict()),
+    ("simple.hexray", hx.overlay_text(320, 240, want_aa=False), dict(mode=hx.MODE_SINGLE)),
+    ("cornell_box.hexray", hx.overlay_text(96, 72, num_paths=4), dict()),
+]
+
+
+@pytest.mark.parametrize("scene,ov,fp", SAH_SCENES)
+def test_sah_tree_renders_the_reference_trees_image(gpu, scene, ov, fp):
+    """Same walk, same leaf rule, same triangle test, other split planes: the frame must match the oracle (which walks the
+    reference's tree) to the same 1e-4 bar, and the frame of the reference tree on the GPU almost everywhere exactly."""
+    hs = hx.HostScene(scene_path(scene), ov)
+    ref_tree = hx.DeviceScene(hs).render(hx.frame_params(**fp))
+    sah = hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
+    p = hx.frame_params(collect_counters=True, **fp)
+    g = sah.render(p)
+    c = sah.counters()
+    o, oc = oracle_render(hs, hx.frame_params(**fp))
+    assert np.all(rms(g, o) <= RMS_BAR), rms(g, o)
+    assert np.all(rms(g, ref_tree) <= RMS_BAR), rms(g, ref_tree)
+    differing = int((np.abs(g - ref_tree).max(axis=2) > 1e-5).sum())
+    assert differing <= max(2, g.shape[0] * g.shape[1] // 2000), differing   # ties on shared edges only
+    # what the frame is made of does not depend on the tree: same rays, same shadow queries, same texture / environment reads
+    for k in ("camera_samples", "raycasts", "shadow_queries", "node_tests", "env_bilinear"):
+        assert c[k] == oc[k], (k, c[k], oc[k])
+    assert c["box_test_mismatch"] == 0
+    assert c["tri_tests"] < oc["tri_tests"]   # and it is the better tree
+
+
+def test_sah_tree_statistics_and_errors(gpu):
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(64, 48))
+    ref, sah = hx.DeviceScene(hs), hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
+    for m in range(3):
+        n0, l0, d0 = ref.tree_stats(m)
+        n1, l1, d1 = sah.tree_stats(m)
+        assert n0 % 2 == 1 and n1 % 2 == 1 and d1 <= 40 and l1 > 0
+    assert ref.tree_stats(1)[0] in (15, 1467, 6007)
+    with pytest.raises(hx.HipError):
+        hx.DeviceScene(hs, accel=7)
