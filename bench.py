@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="meshes16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sah-side", action="store_true", help="skip the SAH-tree side measurement (profiling runs: one kernel configuration only)")
     ap.add_argument("--accel", default="reference", choices=["reference", "sah"],
                     help="kd-trees walked by the timed frames: the reference's own (default) or the module's SAH rebuild")
     args = ap.parse_args()
@@ -221,7 +222,7 @@ def main():
                                   "kernel_ms": round(kernel_ms_mean, 4), "note": "per-rank kernel time of rank 0; counters are collected at N=1 only"}
         # outside the timed region, reported separately: scene preparation
         result["scene_prep_s"] = {"host_parse_kd_build_flatten": round(host_prep_s, 3), "hxr_scene_create": round(device_prep_s, 3)}
-        if world == 1 and accel == hx.ACCEL_REFERENCE:
+        if world == 1 and accel == hx.ACCEL_REFERENCE and not args.no_sah_side:
             # SURVEY.md 8(f) rank 1, measured beside the headline: the same frame through the module's SAH kd-trees
             ref_frame = frame.clone()
             alt = hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
