@@ -47,6 +47,9 @@ enum {
 	HC_HFCALL, HC_HFHIGH, HC_HFHEIGHT, HC_HFTRI, HC_HFNORM, HC_AA, HC_BOXMISMATCH, HC_NUM
 };
 
+// lanes of the wave for which `pred` holds: the compare's own mask (HIP's __ballot() goes through an int and a second compare)
+#define hxr_ballot(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64(pred))
+
 struct d3 { double x, y, z; };
 struct f3 { float x, y, z; };
 
@@ -174,7 +177,7 @@ HXR_DEV bool box_hit(const Box& b, d3 o, d3 d, d3 inv)
 	double tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmin(tz0, tz1));
 	double tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmax(tz0, tz1));
 	bool r = tn <= tf && tf >= 0;
-	if (__ballot(!r)) r = r || box_holds(b, o);   // the inflated inside() shortcut only matters for lanes the slabs reject
+	if (hxr_ballot(!r)) r = r || box_holds(b, o);   // the inflated inside() shortcut only matters for lanes the slabs reject
 	return r;
 }
 
@@ -476,7 +479,7 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	g.t = HXR_INF;
 	g.tri = -1;
 	bool in_root = box_test<COUNT>(cb, o, d, inv, tl);
-	unsigned long long alive = __ballot(in_root);   // lanes still searching
+	unsigned long long alive = hxr_ballot(in_root);   // lanes still searching
 	if (!alive) { tl.template lap<PH_MESH>(); return false; }
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
@@ -496,13 +499,12 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		if (axis == HXR_KD_LEAF) {
 			bool here = leaf_query<COUNT>(S, M, R.first, ac >> 2, (mask & me) != 0, cb, o, d, nd, g, st, tl);
 			found = found || here;
-			alive &= ~__ballot(here);
+			alive &= ~hxr_ballot(here);
 		} else {
 			const double split = R.split;
 			const int left = R.first;
 			const HxrKdPair kids = *(const HxrKdPair*)(kd + left);   // in flight while the first child's box is being tested
-			bool right_first = (mask & me) && comp(o, axis) > split;
-			unsigned long long rm = __ballot(right_first), lm = mask & ~rm;
+			unsigned long long rm = hxr_ballot(comp(o, axis) > split) & mask, lm = mask & ~rm;   // lanes whose near child is the right one
 			// the visits of this node's children, in execution order: the first one directly (its box derives from
 			// this node's, no load needed), the others through the stack
 			const bool go_left = lm != 0;
@@ -514,20 +516,21 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 				st.node[sp] = go_left ? left + 1 : left; st.mask_lo[sp] = (uint32_t)next_mask; st.mask_hi[sp] = (uint32_t)(next_mask >> 32); sp++;
 			}
 			// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
+			const int moved = go_left ? axis : axis + 3;   // which of the six bounds becomes the split position
 			Box nb;
-			nb.lo.x = (!go_left && axis == 0) ? split : cb.lo.x;
-			nb.lo.y = (!go_left && axis == 1) ? split : cb.lo.y;
-			nb.lo.z = (!go_left && axis == 2) ? split : cb.lo.z;
-			nb.hi.x = (go_left && axis == 0) ? split : cb.hi.x;
-			nb.hi.y = (go_left && axis == 1) ? split : cb.hi.y;
-			nb.hi.z = (go_left && axis == 2) ? split : cb.hi.z;
+			nb.hi.x = moved == 0 ? split : cb.hi.x;
+			nb.hi.y = moved == 1 ? split : cb.hi.y;
+			nb.hi.z = moved == 2 ? split : cb.hi.z;
+			nb.lo.x = moved == 3 ? split : cb.lo.x;
+			nb.lo.y = moved == 4 ? split : cb.lo.y;
+			nb.lo.z = moved == 5 ? split : cb.lo.z;
 			// first child of the node just entered: nobody has found anything since `mask` was formed
 			bool pass = false;
 			if (next_mask & me) {
 				pass = box_test<COUNT>(nb, o, d, inv, tl);
 				if (pass) tl.add(HC_KD);
 			}
-			unsigned long long m2 = __ballot(pass);
+			unsigned long long m2 = hxr_ballot(pass);
 			if (m2) {
 				R = go_left ? kids.kid[0] : kids.kid[1];
 				cb = nb;
@@ -550,7 +553,7 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 				pass = box_test<COUNT>(pb, o, d, inv, tl);
 				if (pass) tl.add(HC_KD);
 			}
-			unsigned long long m2 = __ballot(pass);
+			unsigned long long m2 = hxr_ballot(pass);
 			if (m2) {
 				R = C;
 				cb = pb;
@@ -709,7 +712,7 @@ HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, do
 		d3 oc = mk3(N.cull_lo[0], N.cull_lo[1], N.cull_lo[2]) - o;   // cull_lo = centre, cull_hi[0] = radius^2
 		double along = dot(oc, d), oc2 = len2(oc), r2 = N.cull_hi[0];
 		bool reach = !(oc2 - along * along > r2) && !(along < 0 && oc2 > r2);
-		if (!__ballot(reach)) {
+		if (!hxr_ballot(reach)) {
 			if (N.geom_type == HXR_GEOM_MESH) tl.add(HC_BBOX);
 			if (N.geom_type == HXR_GEOM_HEIGHTFIELD) tl.add(HC_HFCALL);
 			return false;
@@ -1730,7 +1733,7 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, c
 						if (fabsf(fminf(1.0f, me[c]) - fminf(1.0f, nb[c])) > 0.075f) { need = true; break; }
 				}
 		}
-		unsigned long long mask = __ballot(need);
+		unsigned long long mask = hxr_ballot(need);
 		int lane = threadIdx.x & 63;
 		int base = 0;
 		if (lane == 0 && mask) base = atomicAdd(count, __popcll(mask));
