@@ -117,6 +117,7 @@ def main():
         slots = padded_tiles_per_rank(W, H, TILE, world)
         local = torch.zeros(slots * TILE * TILE * 3, dtype=torch.float32, device="cuda")
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+        landing = torch.empty(world * local.numel(), dtype=torch.float32, device="cuda") if rank == 0 and not rehearsal else None
         params = hx.frame_params(tile_size=TILE, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
 
         def step():
@@ -126,7 +127,7 @@ def main():
                 got = gather_tiles(local.cpu(), world, rank)
                 gathered = got.cuda() if rank == 0 else None
             else:
-                gathered = gather_tiles(local, world, rank)
+                gathered = gather_tiles(local, world, rank, out=landing)
             if rank == 0:
                 ds.assemble_frame(params, gathered.data_ptr(), slots * TILE * TILE * 12, frame.data_ptr(), W * 12, stream)
 

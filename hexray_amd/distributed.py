@@ -28,18 +28,22 @@ def padded_tiles_per_rank(width: int, height: int, tile: int, world: int) -> int
     return shard_tile_count(width, height, tile, 0, world)
 
 
-def gather_tiles(local, world: int, rank: int, group=None):
+def gather_tiles(local, world: int, rank: int, group=None, out=None):
     """Collect every rank's tile buffer on rank 0.  ``local`` is a 1-D float32 torch tensor of the padded
-    per-rank size; returns the rank-major concatenation on rank 0, ``None`` elsewhere."""
+    per-rank size; returns the rank-major concatenation on rank 0, ``None`` elsewhere.  ``out`` (rank 0): a
+    reusable 1-D tensor of ``world * local.numel()`` elements that receives the ranks' buffers in place (the
+    collective writes straight into its slices: no per-frame allocation, no concatenation pass)."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return local
     if rank == 0:
-        parts = [torch.empty_like(local) for _ in range(world)]
+        if out is None:
+            out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        parts = list(out.view(world, local.numel()).unbind(0))
         dist.gather(local, gather_list=parts, dst=0, group=group)
-        return torch.cat(parts)
+        return out
     dist.gather(local, gather_list=None, dst=0, group=group)
     return None
 
