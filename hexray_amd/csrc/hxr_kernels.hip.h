@@ -111,7 +111,11 @@ struct Tally {
 #ifdef HXR_PHASE_TIMERS
 	uint64_t ph[PH_NUM], t0;
 	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; for (int i = 0; i < PH_NUM; i++) ph[i] = 0; t0 = __builtin_readcyclecounter(); }
+#ifdef HXR_PACKET_CLOCKS
+	template <int PHASE> HXR_DEV void lap() {}
+#else
 	template <int PHASE> HXR_DEV void lap() { uint64_t now = __builtin_readcyclecounter(); ph[PHASE] += now - t0; t0 = now; }
+#endif
 #else
 	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; }
 	template <int PHASE> HXR_DEV void lap() {}
@@ -1602,6 +1606,9 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			if (!got) break;
 		}
 		tl.template lap<PH_DISPENSE>();
+#if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
+		const uint64_t packet_t0 = __builtin_readcyclecounter();
+#endif
 		const uint32_t chunk = batch_pos++;
 		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
 		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
@@ -1670,10 +1677,31 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			dst[2] = acc.z;
 		}
 		tl.template lap<PH_REDUCE>();
+#if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
+		{   // distribution of packet durations instead of the phase sums: slots = {sum, max, count, >= 4x mean-ish thresholds}
+			const uint64_t dt = __builtin_readcyclecounter() - packet_t0;
+			tl.ph[0] += dt;
+			if (dt > tl.ph[1]) tl.ph[1] = dt;
+			tl.ph[2] += 1;
+			if (dt > 1000000ull) tl.ph[3] += 1;    // > 1 M shader clocks (~0.5 ms)
+			if (dt > 4000000ull) tl.ph[4] += 1;    // > 4 M (~2 ms)
+			if (dt > 250000ull) tl.ph[5] += 1;     // > 250 k (~0.12 ms)
+#ifdef HXR_PACKET_CLOCK_IMAGE
+			if (live && sub == lanes_per_pixel - 1) { dst[0] = (float)dt; dst[1] = (float)dt; dst[2] = (float)dt; }   // the frame becomes a cost map
+#endif
+		}
+#endif
 	}
 #ifdef HXR_PHASE_TIMERS
-	if (P.counters && lane == 0)
+	if (P.counters && lane == 0) {
+#ifdef HXR_PACKET_CLOCKS
+		atomicAdd(&P.counters[HC_NUM + 0], (unsigned long long)tl.ph[0]);
+		atomicMax(&P.counters[HC_NUM + 1], (unsigned long long)tl.ph[1]);
+		for (int i = 2; i < PH_NUM; i++) atomicAdd(&P.counters[HC_NUM + i], (unsigned long long)tl.ph[i]);
+#else
 		for (int i = 0; i < PH_NUM; i++) atomicAdd(&P.counters[HC_NUM + i], (unsigned long long)tl.ph[i]);
+#endif
+	}
 #endif
 	if (COUNT && P.counters) {
 		for (int i = 0; i < HC_NUM; i++) {
