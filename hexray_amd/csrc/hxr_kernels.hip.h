@@ -109,12 +109,30 @@ struct Tally {
 	uint32_t c[COUNT ? HC_NUM : 1];
 	HXR_DEV void add(int which, uint32_t n = 1) { if (COUNT) c[which] += n; }
 #ifdef HXR_PHASE_TIMERS
-	uint64_t ph[PH_NUM], t0;
-	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; for (int i = 0; i < PH_NUM; i++) ph[i] = 0; t0 = __builtin_readcyclecounter(); }
+	// One set of accumulators per WAVE, in LDS, updated by the first active lane: a per-lane copy would only advance
+	// while its lane is active and would charge the time a lane sits masked off to whatever phase it wakes up in.
+	volatile unsigned long long* ph;   // PH_NUM phase sums + [PH_NUM] = time of the last lap
+	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; }
+	HXR_DEV void attach(unsigned long long* lds)
+	{
+		ph = lds;
+		if ((threadIdx.x & 63) == 0) {
+			for (int i = 0; i < PH_NUM; i++) lds[i] = 0;
+			lds[PH_NUM] = __builtin_readcyclecounter();
+		}
+	}
 #ifdef HXR_PACKET_CLOCKS
 	template <int PHASE> HXR_DEV void lap() {}
 #else
-	template <int PHASE> HXR_DEV void lap() { uint64_t now = __builtin_readcyclecounter(); ph[PHASE] += now - t0; t0 = now; }
+	template <int PHASE> HXR_DEV void lap()
+	{
+		const unsigned long long now = __builtin_readcyclecounter();
+		const int me = threadIdx.x & 63;
+		if (__builtin_amdgcn_readfirstlane(me) == me) {
+			ph[PHASE] += now - ph[PH_NUM];
+			ph[PH_NUM] = now;
+		}
+	}
 #endif
 #else
 	HXR_DEV void clear() { for (int i = 0; i < (COUNT ? HC_NUM : 1); i++) c[i] = 0; }
@@ -1573,6 +1591,10 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	Tally<COUNT> tl;
 	tl.clear();
+#ifdef HXR_PHASE_TIMERS
+	__shared__ unsigned long long lds_clock[HXR_BLOCK / 64][PH_NUM + 1];
+	tl.attach(lds_clock[wave]);
+#endif
 	const int spp = P.spp;
 	const int lanes_per_pixel = spp < 64 ? spp : 64;          // samples of one pixel resident in the wave
 	const int ppc = P.pixels_per_chunk;                         // 64 / spp for spp <= 64, else 1
@@ -1678,14 +1700,16 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		}
 		tl.template lap<PH_REDUCE>();
 #if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
-		{   // distribution of packet durations instead of the phase sums: slots = {sum, max, count, >= 4x mean-ish thresholds}
-			const uint64_t dt = __builtin_readcyclecounter() - packet_t0;
-			tl.ph[0] += dt;
-			if (dt > tl.ph[1]) tl.ph[1] = dt;
-			tl.ph[2] += 1;
-			if (dt > 1000000ull) tl.ph[3] += 1;    // > 1 M shader clocks (~0.5 ms)
-			if (dt > 4000000ull) tl.ph[4] += 1;    // > 4 M (~2 ms)
-			if (dt > 250000ull) tl.ph[5] += 1;     // > 250 k (~0.12 ms)
+		{   // distribution of packet durations instead of the phase sums: slots = {sum, max, count, three thresholds}
+			const unsigned long long dt = __builtin_readcyclecounter() - packet_t0;
+			if (lane == 0) {
+				tl.ph[0] += dt;
+				if (dt > tl.ph[1]) tl.ph[1] = dt;
+				tl.ph[2] += 1;
+				if (dt > 1000000ull) tl.ph[3] += 1;    // > 1 M shader clocks (~0.5 ms)
+				if (dt > 4000000ull) tl.ph[4] += 1;    // > 4 M (~2 ms)
+				if (dt > 250000ull) tl.ph[5] += 1;     // > 250 k (~0.12 ms)
+			}
 #ifdef HXR_PACKET_CLOCK_IMAGE
 			if (live && sub == lanes_per_pixel - 1) { dst[0] = (float)dt; dst[1] = (float)dt; dst[2] = (float)dt; }   // the frame becomes a cost map
 #endif
@@ -1730,6 +1754,10 @@ __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
 	S.hot = a_hot;
 	S.hot_ids = a_hot_ids;
 	Tally<false> tl;
+#ifdef HXR_PHASE_TIMERS
+	__shared__ unsigned long long lds_clock[PH_NUM + 1];
+	tl.attach(lds_clock);
+#endif
 	d3 o = ld3(S.camera.pos), tlc = ld3(S.camera.top_left);
 	d3 through = tlc + (ld3(S.camera.top_right) - tlc) * ((W * 0.5) / (double)W) + (ld3(S.camera.bottom_left) - tlc) * ((H * 0.5) / (double)H);
 	d3 d = unit(through - o);

@@ -11,10 +11,20 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 scene_name, ov, desc = bench.WORKLOADS[wl]
 hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
 hx.init(0)
-ds = hx.DeviceScene(hs)
+ds = hx.DeviceScene(hs, accel=hx.ACCEL_SAH if os.environ.get('HXR_ACCEL') == 'sah' else hx.ACCEL_REFERENCE)
 p = hx.frame_params(tile_size=32)
+shard = os.environ.get("HXR_SHARD")   # "rank,count": render one shard only (a single tile when count = number of tiles)
+if shard:
+    import torch
+    r, c = (int(v) for v in shard.split(","))
+    p = hx.frame_params(tile_size=32, shard_rank=r, shard_count=c, layout=hx.LAYOUT_TILES)
+    buf = torch.zeros(ds.output_bytes(p, 0) // 4 + 16, dtype=torch.float32, device="cuda")
 ms = []
 for i in range(frames):
-    ds.render(p)
+    if shard:
+        ds.render_device(p, buf.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    else:
+        ds.render(p)
     ms.append(ds.last_kernel_ms())
 print(wl, "kernel ms:", " ".join("%.3f" % m for m in ms))

@@ -11,7 +11,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "meshes16"
 scene_name, ov, desc = bench.WORKLOADS[wl]
 hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
 hx.init(0)
-ds = hx.DeviceScene(hs)
+ds = hx.DeviceScene(hs, accel=hx.ACCEL_SAH if os.environ.get('HXR_ACCEL') == 'sah' else hx.ACCEL_REFERENCE)
 W, H, T = hs.settings.frame_width, hs.settings.frame_height, 32
 for world in (1, 2, 4, 8):
     slots = padded_tiles_per_rank(W, H, T, world)
