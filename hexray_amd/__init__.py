@@ -51,7 +51,7 @@ ACCEL_REFERENCE, ACCEL_SAH = 0, 1
 class SceneOptions(ctypes.Structure):
     """hxr_scene_options (include/hexray_hip.h)."""
 
-    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32)]
+    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32), ("no_adaptive_schedule", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
 class Counters(ctypes.Structure):
@@ -284,13 +284,13 @@ class DeviceScene:
     """A scene resident in HBM (hxr_scene).  ``accel``: ACCEL_REFERENCE walks the kd-trees of the descriptor (the
     reference's own), ACCEL_SAH rebuilds them with the surface-area heuristic (hxr_scene_create_ex)."""
 
-    def __init__(self, host_scene: HostScene, accel: int = 0):
+    def __init__(self, host_scene: HostScene, accel: int = 0, adaptive_schedule: bool = True):
         if _initialised_device is None:
             init(0)
-        if accel == ACCEL_REFERENCE:
+        if accel == ACCEL_REFERENCE and adaptive_schedule:
             self._s = hip_lib().hxr_scene_create(host_scene.desc)
         else:
-            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel)
+            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel, 0 if adaptive_schedule else 1, 0)
             self._s = hip_lib().hxr_scene_create_ex(host_scene.desc, ctypes.byref(opt))
         if not self._s:
             raise HipError("hxr_scene_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))

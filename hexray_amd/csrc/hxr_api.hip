@@ -83,6 +83,14 @@ struct hxr_scene {
 	int32_t* d_extra = nullptr;     size_t extra_capacity = 0;
 	uint32_t* d_work = nullptr;     // [0..255] dispenser shards pass 1 / MC, [256..511] dispenser shards pass 3, [512] aa count
 	unsigned long long* d_counters = nullptr;
+	// adaptive schedule (see HxrLaunch::sched_*): cost history of the last frame and what it was a frame of
+	bool adaptive = true;
+	uint32_t* d_sched_cost = nullptr;   size_t sched_cost_cap = 0;     // chunks
+	uint8_t* d_sched_flags = nullptr;   size_t sched_flags_cap = 0;    // chunks
+	uint32_t* d_sched_items = nullptr;  size_t sched_items_cap = 0;    // pixels
+	unsigned long long* d_sched_ctl = nullptr;                         // [0] total cost, then as uint32: [2] tier a, [3] tier b, [4] ticket
+	struct SchedKey { int W, H, mode, spp, tile, rank, count; uint32_t chunks; } sched_key = {0, 0, 0, 0, 0, 0, 0, 0};
+	bool sched_history = false;
 	uint8_t* d_lut = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
@@ -368,6 +376,44 @@ void halo_pixels(const Plan& p, std::vector<int32_t>& out)
 	}
 }
 
+// Adaptive schedule: classify the chunks by what they cost in the previous frame of the same shape (if there was one) and
+// point the launch at the lists; the render kernel records this frame's costs for the next one.
+int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pixels, hipStream_t st)
+{
+	const uint32_t n = L.num_chunks;
+	int rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)n * sizeof(uint32_t));
+	if (!rc) rc = ensure((void**)&s->d_sched_flags, &s->sched_flags_cap, (size_t)n);
+	if (!rc) rc = ensure((void**)&s->d_sched_items, &s->sched_items_cap, (size_t)num_pixels * sizeof(uint32_t));
+	if (rc) return rc;
+	if (!s->d_sched_ctl) HIP_TRY(hipMalloc((void**)&s->d_sched_ctl, 64));
+	const hxr_scene::SchedKey key = {p.W, p.H, p.mode, p.spp, p.tile, p.rank, p.count, n};
+	const bool usable = s->sched_history && memcmp(&key, &s->sched_key, sizeof key) == 0;
+	HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
+	if (usable) {
+		const int grid = (int)std::min<uint32_t>((n + 255u) / 256u, 1024u);
+		// thresholds in multiples of the mean chunk cost: split into one-pixel packets / start first as a whole
+		uint32_t split_x = 16, first_x = 8;
+		if (const char* e = getenv("HXR_SCHED_SPLIT_X")) split_x = (uint32_t)atoi(e);   // developer aids
+		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
+		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
+		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
+		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, s->d_sched_flags, s->d_sched_items, (uint32_t*)s->d_sched_ctl + 2);
+		HIP_TRY(hipGetLastError());
+	} else {
+		HIP_TRY(hipMemsetAsync(s->d_sched_cost, 0, (size_t)n * sizeof(uint32_t), st));
+		HIP_TRY(hipMemsetAsync(s->d_sched_flags, 0, (size_t)n, st));
+	}
+	L.sched_cost = s->d_sched_cost;
+	L.sched_flags = s->d_sched_flags;
+	L.sched_items = s->d_sched_items;
+	L.sched_counts = (const uint32_t*)s->d_sched_ctl + 2;
+	L.sched_ticket = (uint32_t*)s->d_sched_ctl + 4;
+	L.sched_capacity = num_pixels;
+	s->sched_key = key;
+	s->sched_history = true;
+	return 0;
+}
+
 int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, size_t stride, hipStream_t st)
 {
 	Plan p;
@@ -406,6 +452,10 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		L.out_stride = stride;
 		L.out_tiles = p.layout == HXR_LAYOUT_TILES;
 		L.work_counter = s->d_work;
+		if (s->adaptive && L.num_chunks >= 4096) {   // small frames have no tail worth scheduling
+			rc = prepare_schedule(s, p, L, tile_pixels, st);
+			if (rc) return rc;
+		}
 		return launch_render(s, L, counters, st, true);
 	}
 
@@ -513,7 +563,9 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		accel = opt->accel;
 		if (accel != HXR_ACCEL_REFERENCE && accel != HXR_ACCEL_SAH) { set_err("unknown acceleration structure %d", accel); return nullptr; }
 	}
+	const bool adaptive = !(opt && opt->no_adaptive_schedule) && !getenv("HXR_NO_ADAPTIVE_SCHEDULE");
 	hxr_scene* s = new hxr_scene;
+	s->adaptive = adaptive;
 	auto fail = [&]() -> hxr_scene* { hxr_scene_destroy(s); return nullptr; };
 	HxrSceneDev& V = s->host_view;
 	memset(&V, 0, sizeof V);
@@ -860,6 +912,10 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_scratch) (void)hipFree(s->d_scratch);
 	if (s->d_aa_list) (void)hipFree(s->d_aa_list);
 	if (s->d_extra) (void)hipFree(s->d_extra);
+	if (s->d_sched_cost) (void)hipFree(s->d_sched_cost);
+	if (s->d_sched_flags) (void)hipFree(s->d_sched_flags);
+	if (s->d_sched_items) (void)hipFree(s->d_sched_items);
+	if (s->d_sched_ctl) (void)hipFree(s->d_sched_ctl);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
 	delete s;

@@ -125,4 +125,13 @@ struct HxrLaunch {
 	unsigned long long* counters;   // hxr_counters as 64-bit words, or nullptr
 	uint32_t num_chunks;
 	int32_t pixels_per_chunk;  // pixels one 64-lane chunk covers
+	// Feedback-directed packet schedule (hxr_api.hip, "adaptive schedule"): the shader-clock duration of every chunk of THIS
+	// frame goes to sched_cost; chunks that were expensive in the PREVIOUS frame of the same shape are listed pixel by
+	// pixel in sched_items and handed out first, one pixel per packet.  All null / zero when the feature is off.
+	uint32_t* sched_cost;            // [num_chunks]
+	const uint8_t* sched_flags;      // [num_chunks] 1 = listed in sched_items: the ordinary dispenser skips it
+	const uint32_t* sched_items;     // pixel numbers: the heaviest tier from the front, the second tier from the back
+	const uint32_t* sched_counts;    // [0] items in the first tier, [1] items in the second
+	uint32_t* sched_ticket;          // dispenser of the listed items
+	uint32_t sched_capacity;         // entries of sched_items
 };

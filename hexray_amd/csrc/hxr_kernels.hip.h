@@ -1550,6 +1550,7 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // the render kernel: persistent wavefronts, one ray packet (64 camera samples) per dispenser ticket
 // ------------------------------------------------------------------------------------------------
 #define HXR_BLOCK 256
+#define HXR_SCHED_WHOLE 0x80000000u   // schedule item flag: the whole chunk that starts at this pixel
 #ifndef HXR_SHARDS
 #define HXR_SHARDS 8          // dispenser counters (power of two)
 #endif
@@ -1608,33 +1609,54 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	// A wave drains its home range, then helps with the others.
 	const uint32_t per_shard = ((num_chunks + HXR_SHARDS * HXR_BATCH - 1) / (HXR_SHARDS * HXR_BATCH)) * HXR_BATCH;
 	uint32_t shard = blockIdx.x & (HXR_SHARDS - 1), shards_done = 0, batch_pos = 0, batch_end = 0;
+	// Adaptive schedule: pixels of chunks that were expensive in the previous frame come first, ONE pixel per packet.  An
+	// expensive packet is one whose rays have scattered (reflections inside the crease of a mesh ...): the packet walk then
+	// serves its lanes one after the other, so its duration grows with the number of live lanes -- up to 8 ms for one packet
+	// of the headline frame, which no other wave can help with.  Split four ways and started first, the same pixels finish
+	// in a quarter of the time while the cheap packets fill the machine.  The image does not depend on any of this.
+	const bool scheduled = P.sched_counts != nullptr && P.mode != 2;
+	const uint32_t listed_a = scheduled ? P.sched_counts[0] : 0u, listed_b = scheduled ? P.sched_counts[1] : 0u;
+	bool listed_left = listed_a + listed_b > 0;
 	for (;;) {
-		if (batch_pos >= batch_end) {
-			bool got = false;
-			while (shards_done < HXR_SHARDS) {
-				uint32_t t = 0;
-				if (lane == 0) t = atomicAdd(P.work_counter + shard * HXR_SHARD_STRIDE, (uint32_t)HXR_BATCH);
-				t = __builtin_amdgcn_readfirstlane(t);
-				const uint32_t lo = shard * per_shard, hi = min(lo + per_shard, num_chunks);
-				if (lo < hi && t < hi - lo) {
-					batch_pos = lo + t;
-					batch_end = min(batch_pos + HXR_BATCH, hi);
-					got = true;
-					break;
+		uint32_t single_pixel = 0xffffffffu;   // != ~0: this packet renders only that pixel
+		if (listed_left) {
+			uint32_t t = 0;
+			if (lane == 0) t = atomicAdd(P.sched_ticket, 1u);
+			t = __builtin_amdgcn_readfirstlane(t);
+			if (t < listed_a) single_pixel = P.sched_items[t];
+			else if (t - listed_a < listed_b) single_pixel = P.sched_items[P.sched_capacity - 1u - (t - listed_a)];
+			else listed_left = false;
+		}
+		if (single_pixel == 0xffffffffu) {
+			if (batch_pos >= batch_end) {
+				bool got = false;
+				while (shards_done < HXR_SHARDS) {
+					uint32_t t = 0;
+					if (lane == 0) t = atomicAdd(P.work_counter + shard * HXR_SHARD_STRIDE, (uint32_t)HXR_BATCH);
+					t = __builtin_amdgcn_readfirstlane(t);
+					const uint32_t lo = shard * per_shard, hi = min(lo + per_shard, num_chunks);
+					if (lo < hi && t < hi - lo) {
+						batch_pos = lo + t;
+						batch_end = min(batch_pos + HXR_BATCH, hi);
+						got = true;
+						break;
+					}
+					shard = (shard + 1) & (HXR_SHARDS - 1);
+					shards_done++;
 				}
-				shard = (shard + 1) & (HXR_SHARDS - 1);
-				shards_done++;
+				if (!got) break;
 			}
-			if (!got) break;
+			if (scheduled && P.sched_flags[batch_pos]) { batch_pos++; continue; }   // its pixels were handed out from the list
 		}
 		tl.template lap<PH_DISPENSE>();
-#if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
-		const uint64_t packet_t0 = __builtin_readcyclecounter();
-#endif
-		const uint32_t chunk = batch_pos++;
+		const unsigned long long packet_t0 = __builtin_readcyclecounter();
+		const bool listed = single_pixel != 0xffffffffu;
+		const bool single = listed && !(single_pixel & HXR_SCHED_WHOLE);   // one pixel only; a listed WHOLE chunk is an ordinary packet
+		single_pixel &= ~HXR_SCHED_WHOLE;
+		const uint32_t chunk = listed ? single_pixel / (uint32_t)P.pixels_per_chunk : batch_pos++;
 		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
 		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
-		bool live = slot < ppc;
+		bool live = single ? slot == 0 : slot < ppc;
 		// which pixel
 		int x = 0, y = 0;
 		uint32_t q = 0;
@@ -1643,7 +1665,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			live = live && e < (uint32_t)*P.aa_count;
 			if (live) { int pix = P.aa_list[e]; x = pix % P.W; y = pix / P.W; }
 		} else {
-			q = chunk * (uint32_t)ppc + (uint32_t)slot;
+			q = single ? single_pixel : chunk * (uint32_t)ppc + (uint32_t)slot;
 			uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
 			if (q < tile_pixels) live = live && shard_pixel(P, q, x, y);
 			else {                // halo pixels of a sharded adaptive-AA frame
@@ -1698,6 +1720,10 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			dst[1] = acc.y;
 			dst[2] = acc.z;
 		}
+		if (scheduled && lane == 0) {   // what this chunk cost (a single pixel stands for its ppc-pixel chunk)
+			unsigned long long dt = (__builtin_readcyclecounter() - packet_t0) * (single ? (unsigned long long)ppc : 1ull);
+			atomicMax(P.sched_cost + chunk, (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
+		}
 		tl.template lap<PH_REDUCE>();
 #if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
 		{   // distribution of packet durations instead of the phase sums: slots = {sum, max, count, three thresholds}
@@ -1733,6 +1759,46 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
 			if (lane == 0 && v) atomicAdd(&P.counters[i], (unsigned long long)v);
 		}
+	}
+}
+
+// Adaptive schedule, step 1: total cost of the previous frame's chunks.
+__global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t n, unsigned long long* total)
+{
+	unsigned long long s = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += cost[i];
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+}
+
+// Step 2: chunks that cost more than `split_x` times the mean are listed pixel by pixel from the front of `items` (their
+// rays have scattered: a packet of them costs in proportion to its live lanes, so four one-pixel packets on four waves finish
+// in a quarter of the time); chunks above `first_x` times the mean are listed whole, from the back (expensive but coherent:
+// only started early).  `items` has one entry per pixel, so the two lists cannot meet.  `cost` is cleared for the frame
+// about to be rendered.
+__global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc, uint32_t num_pixels, const unsigned long long* total, uint32_t split_x,
+                                       uint32_t first_x, uint32_t resident_waves, uint8_t* flags, uint32_t* items, uint32_t* counts)
+{
+	const unsigned long long mean = *total / (n ? n : 1u);
+	// a packet is worth splitting when it is long against the frame itself: half of what one wave gets through when the work
+	// is spread perfectly (a shard of an 8-GPU frame is eight times shorter than the whole frame, its limit eight times lower)
+	const unsigned long long split_above = max((unsigned long long)split_x * mean, *total / (resident_waves ? resident_waves : 1u) / 2ull);
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const unsigned long long c = cost[i];
+		cost[i] = 0;
+		const uint32_t first = i * ppc;
+		const bool heavy = mean > 0 && c > (unsigned long long)first_x * mean && first < num_pixels;
+		if (heavy) {
+			if (c > split_above && ppc > 1) {
+				const uint32_t cnt = min(ppc, num_pixels - first);
+				const uint32_t at = atomicAdd(counts + 0, cnt);
+				for (uint32_t j = 0; j < cnt; j++) items[at + j] = first + j;
+			} else {
+				const uint32_t at = atomicAdd(counts + 1, 1u);
+				items[num_pixels - 1u - at] = first | HXR_SCHED_WHOLE;
+			}
+		}
+		flags[i] = heavy ? 1 : 0;
 	}
 }
 

@@ -319,6 +319,11 @@ enum hxr_accel {
 typedef struct hxr_scene_options {
 	uint32_t struct_size;     /* sizeof(hxr_scene_options): lets the record grow */
 	int32_t accel;            /* enum hxr_accel */
+	int32_t no_adaptive_schedule; /* 1: hand the ray packets out in frame order every frame.  Default (0): packets that were
+	                             expensive in the previous frame of the same size / mode / shard are started first and split
+	                             into one-pixel packets -- a schedule only, every frame still traces every sample and the
+	                             image does not depend on it ("adaptive schedule") */
+	int32_t reserved_;
 } hxr_scene_options;
 
 /* hxr_scene_create with options (NULL = defaults = hxr_scene_create). */

@@ -266,3 +266,20 @@ def test_sah_tree_statistics_and_errors(gpu):
     assert ref.tree_stats(1)[0] in (15, 1467, 6007)
     with pytest.raises(hx.HipError):
         hx.DeviceScene(hs, accel=7)
+
+
+def test_adaptive_schedule_does_not_change_the_frame(gpu):
+    """From the second frame on the packets are handed out in another order and the expensive ones one pixel at a time
+    (feedback from the previous frame's per-chunk clocks): every frame must stay bit-identical, with and without it."""
+    for ov, fp in ((hx.overlay_text(640, 360, dof=True, num_samples=16), dict()), (hx.overlay_text(640, 360, want_aa=False), dict(mode=hx.MODE_SINGLE))):
+        hs = hx.HostScene(scene_path("meshes.hexray"), ov)
+        plain = hx.DeviceScene(hs, adaptive_schedule=False).render(hx.frame_params(**fp))
+        ds = hx.DeviceScene(hs)
+        frames = [ds.render(hx.frame_params(**fp)) for _ in range(4)]
+        for f in frames:
+            assert np.array_equal(f, plain)
+        ds.render(hx.frame_params(collect_counters=True, **fp))          # the counted build follows the same lists
+        c = ds.counters()
+        o, oc = oracle_render(hs, hx.frame_params(**fp))
+        for k in ("camera_samples", "raycasts", "shadow_queries", "node_tests", "bbox_tests", "tri_tests"):
+            assert c[k] == oc[k], (k, c[k], oc[k])

@@ -1,6 +1,7 @@
 #!/bin/bash
-for lib in hexray_amd/lib/libhexray_hip.so hexray_amd/lib/libhexray_hip_rev.so hexray_amd/lib/libhexray_hip_prev.so; do for accel in ref sah; do
-  echo "== $lib HXR_ACCEL=$accel"
-  HXR_HIP_LIB=$PWD/$lib HXR_ACCEL=$accel timeout -k 10 200 python3 tools/run_frame.py meshes16 4
-  HXR_HIP_LIB=$PWD/$lib HXR_ACCEL=$accel timeout -k 10 200 python3 tools/shard_time.py meshes16 | grep "world 8\|world 2"
-done; done
+for accel in ref sah; do
+  echo "== HXR_ACCEL=$accel"
+  HXR_ACCEL=$accel timeout -k 10 200 python3 tools/run_frame.py meshes16 6
+  HXR_ACCEL=$accel timeout -k 10 200 python3 tools/shard_time.py meshes16 | grep "world"
+done
+for w in simple1 heightfield16 smallpt16 cornell16 kdtree16; do python3 tools/run_frame.py $w 5; HXR_NO_ADAPTIVE_SCHEDULE=1 python3 tools/run_frame.py $w 5; done
