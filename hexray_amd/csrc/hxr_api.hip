@@ -87,8 +87,10 @@ struct hxr_scene {
 	bool adaptive = true;
 	uint32_t* d_sched_cost = nullptr;   size_t sched_cost_cap = 0;     // chunks
 	uint8_t* d_sched_flags = nullptr;   size_t sched_flags_cap = 0;    // chunks
-	uint32_t* d_sched_items = nullptr;  size_t sched_items_cap = 0;    // pixels
-	unsigned long long* d_sched_ctl = nullptr;                         // [0] total cost, then as uint32: [2] tier a, [3] tier b, [4] ticket
+	uint32_t* d_sched_items = nullptr;  size_t sched_items_cap = 0;    // pixels + room for the sample-split parts
+	float* d_sched_side = nullptr;      size_t sched_side_cap = 0;     // HXR_PART_SLOTS x lanes per pixel x 3
+	uint32_t* d_sched_part = nullptr;                                  // [0..SLOTS) parts done, [SLOTS..2*SLOTS) pixel of the slot
+	unsigned long long* d_sched_ctl = nullptr;                         // [0] total cost, then as uint32: [2] listed from the front, [3] from the back, [4] part slots, [5] ticket
 	struct SchedKey { int W, H, mode, spp, tile, rank, count; uint32_t chunks; } sched_key = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool sched_history = false;
 	uint8_t* d_lut = nullptr;
@@ -383,8 +385,16 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	const uint32_t n = L.num_chunks;
 	int rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)n * sizeof(uint32_t));
 	if (!rc) rc = ensure((void**)&s->d_sched_flags, &s->sched_flags_cap, (size_t)n);
-	if (!rc) rc = ensure((void**)&s->d_sched_items, &s->sched_items_cap, (size_t)num_pixels * sizeof(uint32_t));
+	// sample-split level: Monte-Carlo frames whose pixel fills a quarter wave or more with one round of samples
+	const int lanes_per_pixel = L.spp < 64 ? L.spp : 64;
+	const uint32_t part_groups = (L.mode == 1 && L.spp <= 64 && lanes_per_pixel >= 2 * HXR_PART_LANES && lanes_per_pixel % HXR_PART_LANES == 0 && !getenv("HXR_SCHED_NO_PARTS"))
+	                                 ? (uint32_t)(lanes_per_pixel / HXR_PART_LANES) : 0u;
+	const uint32_t capacity = num_pixels + HXR_PART_SLOTS * 16u;
+	if (!rc) rc = ensure((void**)&s->d_sched_items, &s->sched_items_cap, (size_t)capacity * sizeof(uint32_t));
+	if (!rc) rc = ensure((void**)&s->d_sched_side, &s->sched_side_cap, (size_t)HXR_PART_SLOTS * 64 * 3 * sizeof(float));
 	if (rc) return rc;
+	if (!s->d_sched_part) HIP_TRY(hipMalloc((void**)&s->d_sched_part, (size_t)HXR_PART_SLOTS * 2 * sizeof(uint32_t)));
+	HIP_TRY(hipMemsetAsync(s->d_sched_part, 0, (size_t)HXR_PART_SLOTS * sizeof(uint32_t), st));
 	if (!s->d_sched_ctl) HIP_TRY(hipMalloc((void**)&s->d_sched_ctl, 64));
 	const hxr_scene::SchedKey key = {p.W, p.H, p.mode, p.spp, p.tile, p.rank, p.count, n};
 	const bool usable = s->sched_history && memcmp(&key, &s->sched_key, sizeof key) == 0;
@@ -397,7 +407,8 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
 		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
-		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, s->d_sched_flags, s->d_sched_items, (uint32_t*)s->d_sched_ctl + 2);
+		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
+		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
 		HIP_TRY(hipGetLastError());
 	} else {
 		HIP_TRY(hipMemsetAsync(s->d_sched_cost, 0, (size_t)n * sizeof(uint32_t), st));
@@ -407,8 +418,12 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	L.sched_flags = s->d_sched_flags;
 	L.sched_items = s->d_sched_items;
 	L.sched_counts = (const uint32_t*)s->d_sched_ctl + 2;
-	L.sched_ticket = (uint32_t*)s->d_sched_ctl + 4;
-	L.sched_capacity = num_pixels;
+	L.sched_ticket = (uint32_t*)s->d_sched_ctl + 5;
+	L.sched_capacity = capacity;
+	L.sched_side = s->d_sched_side;
+	L.sched_part_done = s->d_sched_part;
+	L.sched_part_pixels = s->d_sched_part + HXR_PART_SLOTS;
+	L.sched_part_groups = (int32_t)part_groups;
 	s->sched_key = key;
 	s->sched_history = true;
 	return 0;
@@ -916,6 +931,8 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_sched_flags) (void)hipFree(s->d_sched_flags);
 	if (s->d_sched_items) (void)hipFree(s->d_sched_items);
 	if (s->d_sched_ctl) (void)hipFree(s->d_sched_ctl);
+	if (s->d_sched_side) (void)hipFree(s->d_sched_side);
+	if (s->d_sched_part) (void)hipFree(s->d_sched_part);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
 	delete s;

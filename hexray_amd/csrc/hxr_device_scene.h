@@ -134,4 +134,10 @@ struct HxrLaunch {
 	const uint32_t* sched_counts;    // [0] items in the first tier, [1] items in the second
 	uint32_t* sched_ticket;          // dispenser of the listed items
 	uint32_t sched_capacity;         // entries of sched_items
+	// third level of splitting: HXR_PART_LANES samples of one pixel per packet.  The parts leave their sample colours in
+	// sched_side; the part that finishes last (sched_part_done) adds them up in sample order and writes the pixel.
+	float* sched_side;               // [part slot][sample][3]
+	uint32_t* sched_part_done;       // [part slot] parts finished
+	const uint32_t* sched_part_pixels;   // [part slot] pixel number
+	int32_t sched_part_groups;       // parts per pixel (0: level disabled)
 };

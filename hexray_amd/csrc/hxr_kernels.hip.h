@@ -1551,6 +1551,9 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // ------------------------------------------------------------------------------------------------
 #define HXR_BLOCK 256
 #define HXR_SCHED_WHOLE 0x80000000u   // schedule item flag: the whole chunk that starts at this pixel
+#define HXR_SCHED_PART 0x40000000u    // schedule item flag: bits 22..29 = which HXR_PART_LANES samples, bits 0..21 = part slot
+#define HXR_PART_LANES 4
+#define HXR_PART_SLOTS 16384          // pixels that can be split by samples in one frame
 #ifndef HXR_SHARDS
 #define HXR_SHARDS 8          // dispenser counters (power of two)
 #endif
@@ -1651,12 +1654,15 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		tl.template lap<PH_DISPENSE>();
 		const unsigned long long packet_t0 = __builtin_readcyclecounter();
 		const bool listed = single_pixel != 0xffffffffu;
+		const bool part = listed && (single_pixel & HXR_SCHED_PART);        // HXR_PART_LANES samples of one pixel
+		const uint32_t part_slot = single_pixel & 0x3fffffu, part_group = (single_pixel >> 22) & 0xffu;
+		if (part) single_pixel = P.sched_part_pixels[part_slot];
 		const bool single = listed && !(single_pixel & HXR_SCHED_WHOLE);   // one pixel only; a listed WHOLE chunk is an ordinary packet
 		single_pixel &= ~HXR_SCHED_WHOLE;
 		const uint32_t chunk = listed ? single_pixel / (uint32_t)P.pixels_per_chunk : batch_pos++;
 		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
 		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
-		bool live = single ? slot == 0 : slot < ppc;
+		bool live = single ? slot == 0 : slot < ppc;           // lanes that belong to a pixel of this packet
 		// which pixel
 		int x = 0, y = 0;
 		uint32_t q = 0;
@@ -1676,7 +1682,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		}
 		tl.template lap<PH_MAP>();
 		f3 sum = mkf(0, 0, 0);
-		if (live) {
+		if (live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group)) {
 			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
 			for (int rd = 0; rd < rounds; rd++) {
 				int s = sub + rd * 64;
@@ -1696,6 +1702,28 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 				}
 				f3 c = trace_sample<COUNT, F>(S, P.W, P.H, sx, sy, rc, lds_stack[wave], tl);
 				sum = (rd == 0) ? c : sum + c;
+			}
+		}
+		if (part) {
+			// leave this part's sample colours where the pixel's last part will find them; only that one goes on to the sum
+			float* side = P.sched_side + (size_t)part_slot * (size_t)lanes_per_pixel * 3;
+			if (live && (uint32_t)sub / HXR_PART_LANES == part_group) {
+				__hip_atomic_store(side + sub * 3 + 0, sum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(side + sub * 3 + 1, sum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(side + sub * 3 + 2, sum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			__threadfence();
+			uint32_t before = 0;
+			if (lane == 0) before = __hip_atomic_fetch_add(P.sched_part_done + part_slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			before = __builtin_amdgcn_readfirstlane(before);
+			const unsigned long long dt = (__builtin_readcyclecounter() - packet_t0) * (unsigned long long)(ppc * P.sched_part_groups);
+			if (lane == 0) atomicMax(P.sched_cost + chunk, (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
+			if (before + 1u != (uint32_t)P.sched_part_groups) continue;
+			__threadfence();
+			if (live) {   // every lane of the pixel takes its sample's colour (past this CU's L1: other waves wrote them)
+				sum.x = __hip_atomic_load(side + sub * 3 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				sum.y = __hip_atomic_load(side + sub * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				sum.z = __hip_atomic_load(side + sub * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
 		// Combine the samples of each pixel in sample order (the reference adds them one by one, src/main.cpp:372-377).
@@ -1720,7 +1748,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			dst[1] = acc.y;
 			dst[2] = acc.z;
 		}
-		if (scheduled && lane == 0) {   // what this chunk cost (a single pixel stands for its ppc-pixel chunk)
+		if (scheduled && !part && lane == 0) {   // what this chunk cost (a single pixel stands for its ppc-pixel chunk)
 			unsigned long long dt = (__builtin_readcyclecounter() - packet_t0) * (single ? (unsigned long long)ppc : 1ull);
 			atomicMax(P.sched_cost + chunk, (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
 		}
@@ -1777,7 +1805,8 @@ __global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t
 // only started early).  `items` has one entry per pixel, so the two lists cannot meet.  `cost` is cleared for the frame
 // about to be rendered.
 __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc, uint32_t num_pixels, const unsigned long long* total, uint32_t split_x,
-                                       uint32_t first_x, uint32_t resident_waves, uint8_t* flags, uint32_t* items, uint32_t* counts)
+                                       uint32_t first_x, uint32_t resident_waves, uint32_t part_groups, uint8_t* flags, uint32_t* items, uint32_t capacity,
+                                       uint32_t* part_pixels, uint32_t* counts)
 {
 	const unsigned long long mean = *total / (n ? n : 1u);
 	// a packet is worth splitting when it is long against the frame itself: half of what one wave gets through when the work
@@ -1789,13 +1818,22 @@ __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc,
 		const uint32_t first = i * ppc;
 		const bool heavy = mean > 0 && c > (unsigned long long)first_x * mean && first < num_pixels;
 		if (heavy) {
-			if (c > split_above && ppc > 1) {
-				const uint32_t cnt = min(ppc, num_pixels - first);
+			const uint32_t cnt = min(ppc, num_pixels - first);
+			if (part_groups > 0 && c > split_above * ppc) {           // even one pixel of it is too long: HXR_PART_LANES samples per packet
+				for (uint32_t j = 0; j < cnt; j++) {
+					const uint32_t ps = atomicAdd(counts + 2, 1u);
+					if (ps < HXR_PART_SLOTS) {
+						part_pixels[ps] = first + j;
+						const uint32_t at = atomicAdd(counts + 0, part_groups);
+						for (uint32_t g = 0; g < part_groups; g++) items[at + g] = HXR_SCHED_PART | (g << 22) | ps;
+					} else items[atomicAdd(counts + 0, 1u)] = first + j;
+				}
+			} else if (c > split_above && ppc > 1) {
 				const uint32_t at = atomicAdd(counts + 0, cnt);
 				for (uint32_t j = 0; j < cnt; j++) items[at + j] = first + j;
 			} else {
 				const uint32_t at = atomicAdd(counts + 1, 1u);
-				items[num_pixels - 1u - at] = first | HXR_SCHED_WHOLE;
+				items[capacity - 1u - at] = first | HXR_SCHED_WHOLE;
 			}
 		}
 		flags[i] = heavy ? 1 : 0;

@@ -12,11 +12,11 @@ scene_name, ov, desc = bench.WORKLOADS[wl]
 hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
 hx.init(0)
 ds = hx.DeviceScene(hs, accel=hx.ACCEL_SAH if os.environ.get('HXR_ACCEL') == 'sah' else hx.ACCEL_REFERENCE)
-W, H, T = hs.settings.frame_width, hs.settings.frame_height, 32
+W, H, T = hs.settings.frame_width, hs.settings.frame_height, int(os.environ.get("HXR_TILE", "32"))
 for world in (1, 2, 4, 8):
     slots = padded_tiles_per_rank(W, H, T, world)
     buf = torch.zeros(slots * T * T * 3, dtype=torch.float32, device="cuda")
-    for rank in sorted({0, world // 2, world - 1}):
+    for rank in (range(world) if os.environ.get("HXR_ALL_RANKS") else sorted({0, world // 2, world - 1})):
         p = hx.frame_params(tile_size=T, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
         ms = []
         for i in range(5):

@@ -1,7 +1,5 @@
 #!/bin/bash
-for accel in ref sah; do
-  echo "== HXR_ACCEL=$accel"
-  HXR_ACCEL=$accel timeout -k 10 200 python3 tools/run_frame.py meshes16 6
-  HXR_ACCEL=$accel timeout -k 10 200 python3 tools/shard_time.py meshes16 | grep "world"
+for tile in 32 16 8; do
+  echo "== tile $tile"
+  HXR_ALL_RANKS=1 HXR_TILE=$tile timeout -k 10 300 python3 tools/shard_time.py meshes16 | grep "world 8\|world 1"
 done
-for w in simple1 heightfield16 smallpt16 cornell16 kdtree16; do python3 tools/run_frame.py $w 5; HXR_NO_ADAPTIVE_SCHEDULE=1 python3 tools/run_frame.py $w 5; done
