@@ -405,9 +405,11 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		uint32_t split_x = 16, first_x = 8;
 		if (const char* e = getenv("HXR_SCHED_SPLIT_X")) split_x = (uint32_t)atoi(e);   // developer aids
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
+		uint32_t frame_div = 1;   // "long against the frame": more than 1/frame_div of a wave's even share of the work (1 beat 2 and 4 at every N)
+		if (const char* e = getenv("HXR_SCHED_FRAME_DIV")) frame_div = (uint32_t)atoi(e);
 		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
-		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
+		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
 		HIP_TRY(hipGetLastError());
 	} else {
@@ -436,7 +438,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (p.layout == HXR_LAYOUT_FRAME && stride < (size_t)p.W * 12) { set_err("row stride smaller than a row"); return HXR_E_INVALID; }
 	const bool counters = fp->collect_counters != 0;
-#ifdef HXR_PHASE_TIMERS
+#if defined(HXR_PHASE_TIMERS) || defined(HXR_LEAF_STATS)
 	const bool want_counter_buffer = true;    // profiling build: the phase clocks land in hxr_counters.reserved_
 #else
 	const bool want_counter_buffer = counters;
@@ -741,14 +743,17 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	const int32_t* d_sides = nullptr;
 	if (s->arena.upload(d->environment.side_bitmap, 6, &d_sides)) return fail();
 	V.env_sides = d_sides;
-	const HxrSceneDev* dv = nullptr;
-	if (s->arena.upload(&V, 1, &dv)) return fail();
-	s->dev = const_cast<HxrSceneDev*>(dv);
 	void* p = nullptr;
 	if (s->arena.alloc(1024 * sizeof(uint32_t), &p)) return fail();
 	s->d_work = (uint32_t*)p;
 	if (s->arena.alloc(sizeof(hxr_counters), &p)) return fail();
 	s->d_counters = (unsigned long long*)p;
+#ifdef HXR_LEAF_STATS
+	V.dev_stats = s->d_counters + HC_NUM;
+#endif
+	const HxrSceneDev* dv = nullptr;
+	if (s->arena.upload(&V, 1, &dv)) return fail();
+	s->dev = const_cast<HxrSceneDev*>(dv);
 	// sRGB table, built with the same expression as Color::init_sRGB_cache (src/sdl.cpp:406-412, src/color.h:36-47)
 	uint8_t lut[4097];
 	for (int i = 0; i <= 4096; i++) {

@@ -101,6 +101,7 @@ struct HxrSceneDev {
 	const int32_t* env_sides;   // = &environment.side_bitmap[0] of the copy in HBM (indexed at run time; keeps this header in registers)
 	const HxrKdSlim* kd;        // all meshes' kd nodes
 	const HxrKdBox* kd_box;     // their boxes
+	unsigned long long* dev_stats;   // developer builds (-DHXR_LEAF_STATS): six counters in hxr_counters.reserved_; null otherwise
 	const HxrTriHot* hot;       // all meshes' hot triangle records
 	const int32_t* hot_ids;     // triangle number (local to its mesh) of each hot record
 };

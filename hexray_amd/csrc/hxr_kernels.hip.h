@@ -426,6 +426,21 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 {
 	bool found = false;
 	tl.template lap<PH_MESH>();
+#ifdef HXR_LEAF_STATS   // developer aid: how many lanes take part in a leaf visit (would testing ray x triangle pairs in parallel pay?)
+	{
+		const unsigned long long part = hxr_ballot(mine);
+		const int k = __popcll(part), me_ = threadIdx.x & 63;
+		if (part && __builtin_amdgcn_readfirstlane(me_) == me_ && S.dev_stats) {
+			atomicAdd(S.dev_stats + 0, (unsigned long long)count);
+			const int coop = 2 + (3 * k) / 2;
+			atomicAdd(S.dev_stats + 1, (unsigned long long)(count < coop ? count : coop));
+			atomicAdd(S.dev_stats + 2, 1ull);
+			atomicAdd(S.dev_stats + 3, (unsigned long long)k);
+			if (k <= 4) atomicAdd(S.dev_stats + 4, (unsigned long long)count);
+			if (k <= 16) atomicAdd(S.dev_stats + 5, (unsigned long long)count);
+		}
+	}
+#endif
 	const HxrTriHot* T = S.hot + (M.hot_first + first);
 	const int32_t* ids = S.hot_ids + (M.hot_first + first);
 	if (mine) {
@@ -1805,13 +1820,13 @@ __global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t
 // only started early).  `items` has one entry per pixel, so the two lists cannot meet.  `cost` is cleared for the frame
 // about to be rendered.
 __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc, uint32_t num_pixels, const unsigned long long* total, uint32_t split_x,
-                                       uint32_t first_x, uint32_t resident_waves, uint32_t part_groups, uint8_t* flags, uint32_t* items, uint32_t capacity,
+                                       uint32_t first_x, uint32_t resident_waves, uint32_t frame_div, uint32_t part_groups, uint8_t* flags, uint32_t* items, uint32_t capacity,
                                        uint32_t* part_pixels, uint32_t* counts)
 {
 	const unsigned long long mean = *total / (n ? n : 1u);
-	// a packet is worth splitting when it is long against the frame itself: half of what one wave gets through when the work
+	// a packet is worth splitting when it is long against the frame itself: as long as what one wave gets through when the work
 	// is spread perfectly (a shard of an 8-GPU frame is eight times shorter than the whole frame, its limit eight times lower)
-	const unsigned long long split_above = max((unsigned long long)split_x * mean, *total / (resident_waves ? resident_waves : 1u) / 2ull);
+	const unsigned long long split_above = max((unsigned long long)split_x * mean, *total / (resident_waves ? resident_waves : 1u) / (frame_div ? frame_div : 1u));
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const unsigned long long c = cost[i];
 		cost[i] = 0;
