@@ -887,6 +887,24 @@ int hxr_quantize_srgb8(const float* d_frame, size_t row_stride_bytes, int width,
 	return 0;
 }
 
+int hxr_sah_build(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf, int64_t* num_nodes,
+                  int64_t* num_leaf, int* max_depth)
+{
+	if (!d || mesh < 0 || mesh >= d->num_meshes) { set_err("no such mesh"); return HXR_E_INVALID; }
+	const hxr_mesh& m = d->meshes[mesh];
+	if (m.first_triangle < 0 || m.num_triangles < 0 || m.first_triangle + m.num_triangles > d->num_triangles || m.first_vertex < 0) { set_err("bad mesh ranges"); return HXR_E_INVALID; }
+	hxr_sah::SahTree t;
+	hxr_sah::SahBuilder(d->triangles + m.first_triangle, m.num_triangles, d->f64_pool + m.first_vertex * 3, hxr_sah::SahParams()).build(m.bbox_min, m.bbox_max, t);
+	if (num_nodes) *num_nodes = (int64_t)t.nodes.size();
+	if (num_leaf) *num_leaf = (int64_t)t.leaf_indices.size();
+	if (max_depth) *max_depth = t.max_depth;
+	if (!nodes && !leaf_indices) return 0;
+	if (!nodes || !leaf_indices || max_nodes < (int64_t)t.nodes.size() || max_leaf < (int64_t)t.leaf_indices.size()) { set_err("output arrays too small"); return HXR_E_INVALID; }
+	memcpy(nodes, t.nodes.data(), t.nodes.size() * sizeof(hxr_kd_node));
+	if (!t.leaf_indices.empty()) memcpy(leaf_indices, t.leaf_indices.data(), t.leaf_indices.size() * sizeof(int32_t));
+	return 0;
+}
+
 int hxr_scene_tree_stats(const hxr_scene* s, int mesh, int64_t* nodes, int64_t* leaf_entries, int* max_depth)
 {
 	if (!s || mesh < 0 || (size_t)mesh >= s->tree_stats.size()) { set_err("no such mesh"); return HXR_E_INVALID; }

@@ -329,6 +329,12 @@ typedef struct hxr_scene_options {
 /* hxr_scene_create with options (NULL = defaults = hxr_scene_create). */
 hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* desc, const hxr_scene_options* options);
 
+/* Host-only helper (touches no GPU): the kd-tree HXR_ACCEL_SAH builds for mesh `mesh` of `desc`, in the descriptor's own
+ * node format, so that it can be inspected or walked by other code (the CPU tests hand it to the oracle).  Call with
+ * nodes == NULL to learn the sizes; returns 0 or a negative HXR_E_*. */
+int hxr_sah_build(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf_indices,
+                  int64_t* num_nodes, int64_t* num_leaf_indices, int* max_depth);
+
 /* Nodes / leaf entries / depth of the tree actually walked for mesh `mesh` (after an HXR_ACCEL_SAH rebuild these
  * differ from the descriptor's).  The reference prints the same statistics at load (src/mesh.cpp:39-47). */
 int hxr_scene_tree_stats(const hxr_scene* scene, int mesh, int64_t* nodes, int64_t* leaf_entries, int* max_depth);
