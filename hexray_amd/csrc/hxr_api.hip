@@ -339,7 +339,8 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 	} while (0)
 		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h);
 		// occupancy target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel)
-		const unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
+		unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
+		if (s->camera.stereo_separation != 0.0) geom |= HXR_F_EXTRA;   // the anaglyph pair lives in the catch-all variants
 		const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
 		if (!gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
 		else if (!gi && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD, 2);

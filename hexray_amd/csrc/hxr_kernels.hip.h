@@ -1500,7 +1500,9 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	}
 	tl.template lap<PH_LENS>();
 	d3 o, d;
-	if (S.camera.stereo_separation == 0.0) {
+	// the anaglyph pair is compiled into the catch-all variants only (the launcher sends stereo cameras there): a second
+	// inlined copy of the integrator doubles the code of the specialised kernels for a mode none of the config scenes uses
+	if ((F & HXR_F_EXTRA) == 0 || S.camera.stereo_separation == 0.0) {
 		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
 		tl.template lap<PH_GEN>();
 		f3 c = trace_rays<COUNT, F>(S, o, d, rc, st, tl);
