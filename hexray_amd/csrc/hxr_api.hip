@@ -342,10 +342,11 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
 		if (s->camera.stereo_separation != 0.0) geom |= HXR_F_EXTRA;   // the anaglyph pair lives in the catch-all variants
 		const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
-		if (!gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
-		else if (!gi && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD, 2);
-		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI, 2);
-		else if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI, 3);
+		const bool rect = (s->features & HXR_F_RECT) != 0;   // the specialised Whitted variants know PointLights only
+		if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
+		else if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD, 2);
+		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT, 2);
+		else if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT, 3);
 		else if (gi && meshes) HXR_LAUNCH_F(HXR_F_ALL, 3);
 		else if (gi) HXR_LAUNCH_F(HXR_F_ALL, 2);
 		else if (meshes) HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3);
@@ -737,6 +738,8 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (s->arena.upload(d->geometries, (size_t)d->num_geometries, &V.geometries)) return fail();
 	for (int64_t i = 0; i < d->num_shaders; i++)
 		if (d->shaders[i].type == HXR_SHADER_REFLECTION && d->shaders[i].glossiness < 1.0f) s->features |= HXR_F_EXTRA;
+	for (int64_t i = 0; i < d->num_lights; i++)
+		if (d->lights[i].type == HXR_LIGHT_RECT) s->features |= HXR_F_RECT;
 	if (s->arena.upload(d->textures, (size_t)d->num_textures, &V.textures)) return fail();
 	if (s->arena.upload(d->shaders, (size_t)d->num_shaders, &V.shaders)) return fail();
 	if (s->arena.upload(d->layers, (size_t)d->num_layers, &V.layers)) return fail();

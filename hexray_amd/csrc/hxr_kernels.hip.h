@@ -37,8 +37,9 @@
 enum : unsigned {
 	HXR_F_MESH = 1u, HXR_F_HEIGHTFIELD = 2u, HXR_F_SPHERE = 4u, HXR_F_CUBE = 8u,   // geometry kinds besides Plane
 	HXR_F_GI = 16u,                                                                 // pathtrace() instead of raytrace()
-	HXR_F_EXTRA = 32u,                                                              // CSG geometry and glossy Reflection
-	HXR_F_ALL = 63u
+	HXR_F_EXTRA = 32u,                                                              // CSG geometry, glossy Reflection, anaglyph camera
+	HXR_F_RECT = 64u,                                                               // RectLight (every light is a PointLight otherwise)
+	HXR_F_ALL = 127u
 };
 
 // counters (COUNT builds only); order = hxr_counters
@@ -860,9 +861,10 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 // lights
 // ------------------------------------------------------------------------------------------------
 // RectLight::intersect, src/lights.cpp:50-75 (PointLight::intersect returns 0, :27-30)
+template <bool RECT>
 HXR_DEV int light_query(const hxr_light& L, d3 o, d3 d, double& dist)
 {
-	if (L.type != HXR_LIGHT_RECT) return 0;
+	if (!RECT || L.type != HXR_LIGHT_RECT) return 0;
 	d3 s = mulm(o - ld3(L.T.offset), L.T.inv_m);
 	d3 dl = unit_lazy(mulm(d, L.T.inv_m));
 	if (fabs(dl.y) < 1e-12) return 0;
@@ -880,9 +882,10 @@ HXR_DEV int light_query(const hxr_light& L, d3 o, d3 d, double& dist)
 }
 
 // Light::getNthSample: PointLight src/lights.h:88-92, RectLight src/lights.cpp:37-51 ((j1, j2) stand for its two randDouble())
+template <bool RECT>
 HXR_DEV void light_sample(const hxr_light& L, int idx, d3 shade_pos, double j1, double j2, d3& pos, f3& color)
 {
-	if (L.type == HXR_LIGHT_POINT) {
+	if (!RECT || L.type == HXR_LIGHT_POINT) {
 		pos = ld3(L.pos);
 		color = ldf(L.color);
 		return;
@@ -895,9 +898,10 @@ HXR_DEV void light_sample(const hxr_light& L, int idx, d3 shade_pos, double j1, 
 	else color = mkf(0, 0, 0);
 }
 
+template <bool RECT>
 HXR_DEV double light_solid_angle(const hxr_light& L, d3 p)   // RectLight::getSolidAngle, src/lights.cpp:91-102
 {
-	if (L.type != HXR_LIGHT_RECT) return 0;
+	if (!RECT || L.type != HXR_LIGHT_RECT) return 0;
 	d3 dir = unit_lazy(mulm(mk3(0, -1, 0), L.T.m));
 	d3 to_p = p - (mulm(mk3(0, 0, 0), L.T.m) + ld3(L.T.offset));
 	double c = dot(to_p, dir);
@@ -907,7 +911,8 @@ HXR_DEV double light_solid_angle(const hxr_light& L, d3 p)   // RectLight::getSo
 	return L.area * c / ((1 + dd) * (1 + dd));
 }
 
-HXR_DEV int light_num_samples(const hxr_light& L) { return L.type == HXR_LIGHT_RECT ? L.x_subd * L.y_subd : 1; }
+template <bool RECT>
+HXR_DEV int light_num_samples(const hxr_light& L) { return RECT && L.type == HXR_LIGHT_RECT ? L.x_subd * L.y_subd : 1; }
 
 // ------------------------------------------------------------------------------------------------
 // textures / environment
@@ -1117,6 +1122,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 	constexpr bool gi = (F & HXR_F_GI) != 0;   // the launcher picks the variant that matches settings.gi
 	constexpr bool glossy = (F & HXR_F_EXTRA) != 0;
 	constexpr bool gather_records = gi;
+	constexpr bool rect = (F & HXR_F_RECT) != 0;   // RectLight code only where the scene has one
 	StackItem<glossy> stack[HXR_RAY_STACK];
 	int sh_stack[HXR_SHADER_STACK];
 	f3 w_stack[HXR_SHADER_STACK];
@@ -1208,7 +1214,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 			bool blocked = node >= 0;
 			for (int k = 0; k < S.num_lights && !blocked; k++) {
 				double dd = qlimit;
-				if (light_query(S.lights[k], qo, qd, dd)) blocked = true;
+				if (light_query<rect>(S.lights[k], qo, qd, dd)) blocked = true;
 			}
 			if (!blocked) {
 				HXR_WATERFALL(cur_shader, u_sh) HXR_WATERFALL(li, u_li) {
@@ -1237,7 +1243,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 						f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
 						if (intensity(from_light) > 0) {
 							float p_choose = 1.0f / (float)S.num_lights;
-							float p_hit = (float)(1.0f / light_solid_angle(L, hp.ip));
+							float p_hit = (float)(1.0f / light_solid_angle<rect>(L, hp.ip));
 							acc = acc + fdiv(from_light * cur.weight, p_choose * p_hit);
 						}
 					}
@@ -1250,7 +1256,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 			f3 lcol = mkf(0, 0, 0);
 			for (int k = 0; k < S.num_lights; k++) {
 				const hxr_light& L = S.lights[k];
-				int side = light_query(L, qo, qd, bw);
+				int side = light_query<rect>(L, qo, qd, bw);
 				if (side == -1) { lit = true; lcol = mkf(0, 0, 0); }
 				else if (side == 1) { lit = true; lcol = (ldf(L.color) * L.power) * L.scale_factor; }
 			}
@@ -1311,12 +1317,12 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 							li = (int)hxr_below(pick.w0, (uint32_t)S.num_lights);
 							HXR_WATERFALL(li, u_li) {
 								const hxr_light& L = S.lights[u_li];
-								if (light_solid_angle(L, hp.ip) > 0) {
-									int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples(L));
+								if (light_solid_angle<rect>(L, hp.ip) > 0) {
+									int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples<rect>(L));
 									double j1, j2;
 									hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_JITTER), j1, j2);
 									f3 unused;
-									light_sample(L, idx, hp.ip, j1, j2, lp, unused);
+									light_sample<rect>(L, idx, hp.ip, j1, j2, lp, unused);
 									ask_shadow = true;
 								}
 							}
@@ -1371,12 +1377,12 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 					while (li < S.num_lights && !asked) {
 						HXR_WATERFALL(li, u_li) {
 							const hxr_light& L = S.lights[u_li];
-							int n = light_num_samples(L);
+							int n = light_num_samples<rect>(L);
 							if (ls < n) {
 								double j1 = 0, j2 = 0;
-								if (L.type == HXR_LIGHT_RECT)
+								if (rect && L.type == HXR_LIGHT_RECT)
 									hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)u_li * 4096u + (uint32_t)ls), j1, j2);
-								light_sample(L, ls, hp.ip, j1, j2, lp, lc);
+								light_sample<rect>(L, ls, hp.ip, j1, j2, lp, lc);
 								if (is_zero(lc)) ls++;
 								else asked = true;
 							} else {
