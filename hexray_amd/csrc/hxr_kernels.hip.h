@@ -1813,6 +1813,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	}
 }
 
+#ifndef HXR_RENDER_KERNEL_ONLY   // the small kernels below live in hxr_api.hip only
 // Adaptive schedule, step 1: total cost of the previous frame's chunks.
 __global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t n, unsigned long long* total)
 {
@@ -1973,3 +1974,4 @@ __global__ void hxr_quantize_kernel(const float* __restrict__ frame, size_t stri
 		}
 	}
 }
+#endif   // HXR_RENDER_KERNEL_ONLY
