@@ -283,3 +283,22 @@ def test_adaptive_schedule_does_not_change_the_frame(gpu):
         o, oc = oracle_render(hs, hx.frame_params(**fp))
         for k in ("camera_samples", "raycasts", "shadow_queries", "node_tests", "bbox_tests", "tri_tests"):
             assert c[k] == oc[k], (k, c[k], oc[k])
+
+
+STEREO = [
+    ("meshes.hexray", hx.overlay_text(160, 120, want_aa=False, extra="Camera {\nstereoSeparation 0.3\n}\n"), dict(mode=hx.MODE_SINGLE)),
+    ("meshes.hexray", hx.overlay_text(96, 72, dof=True, num_samples=4, extra="Camera {\nstereoSeparation 0.3\n}\n"), dict()),
+    ("heightfield.hexray", hx.overlay_text(120, 68, want_aa=False, extra="Camera {\nstereoSeparation 2\n}\n"), dict(mode=hx.MODE_SINGLE)),
+]
+
+
+@pytest.mark.parametrize("scene,ov,fp", STEREO)
+def test_anaglyph_camera_matches_oracle(gpu, scene, ov, fp):
+    """traceSingleRay's stereo branch (src/main.cpp:234-247): two eyes, channel mix.  It is compiled into the catch-all kernel
+    variants only; the launcher has to route a stereo camera there whatever the geometry."""
+    g, gc, o, oc = both(scene, ov, fp)
+    assert np.all(rms(g, o) <= RMS_BAR), rms(g, o)
+    assert gc["camera_samples"] == oc["camera_samples"] and gc["raycasts"] == oc["raycasts"]
+    hs = hx.HostScene(scene_path(scene), ov.replace("stereoSeparation 0.3", "stereoSeparation 0").replace("stereoSeparation 2", "stereoSeparation 0"))
+    flat = hx.DeviceScene(hs).render(hx.frame_params(**fp))
+    assert rms(g, flat).mean() > 1e-3   # and the pair really is rendered
