@@ -16,18 +16,17 @@
 #include "hxr_accel.h"
 
 // compiled in hxr_kernels_mesh.hip (own scheduling flags)
-extern template __global__ void hxr_render_kernel<false, HXR_F_MESH, 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*,
-                                                                        const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*,
-                                                                        const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, HXR_F_MESH, 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*,
-                                                                       const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*,
-                                                                       const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+
 
 namespace {
 
@@ -357,10 +356,12 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		if (s->camera.stereo_separation != 0.0) geom |= HXR_F_EXTRA;   // the anaglyph pair lives in the catch-all variants
 		const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
 		const bool rect = (s->features & HXR_F_RECT) != 0;   // the specialised Whitted variants know PointLights only
-		if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
-		else if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD, 2);
-		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT, 2);
-		else if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT, 3);
+		const bool refr = (s->features & HXR_F_REFRACT) != 0;
+		if (!gi && !rect && !refr && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
+		else if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, 3);
+		else if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD | HXR_F_REFRACT, 2);
+		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 2);
+		else if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 3);
 		else if (gi && meshes) HXR_LAUNCH_F(HXR_F_ALL, 3);
 		else if (gi) HXR_LAUNCH_F(HXR_F_ALL, 2);
 		else if (meshes) HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3);
@@ -750,8 +751,22 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	}
 	if (s->arena.upload(nodes.data(), nodes.size(), &V.nodes)) return fail();
 	if (s->arena.upload(d->geometries, (size_t)d->num_geometries, &V.geometries)) return fail();
-	for (int64_t i = 0; i < d->num_shaders; i++)
-		if (d->shaders[i].type == HXR_SHADER_REFLECTION && d->shaders[i].glossiness < 1.0f) s->features |= HXR_F_EXTRA;
+	{   // Refraction / glossy Reflection count only where a node's shader tree reaches them (scene files define shaders they do not use)
+		std::vector<char> seen((size_t)d->num_shaders, 0);
+		std::vector<int> todo;
+		for (int64_t i = 0; i < d->num_nodes; i++) todo.push_back(d->nodes[i].shader);
+		while (!todo.empty()) {
+			int sh = todo.back();
+			todo.pop_back();
+			if (sh < 0 || sh >= d->num_shaders || seen[(size_t)sh]) continue;
+			seen[(size_t)sh] = 1;
+			const hxr_shader& S = d->shaders[sh];
+			if (S.type == HXR_SHADER_REFRACTION) s->features |= HXR_F_REFRACT;
+			if (S.type == HXR_SHADER_REFLECTION && S.glossiness < 1.0f) s->features |= HXR_F_EXTRA;
+			if (S.type == HXR_SHADER_LAYERED)
+				for (int k = 0; k < S.num_layers; k++) todo.push_back(d->layers[S.first_layer + k].shader);
+		}
+	}
 	for (int64_t i = 0; i < d->num_lights; i++)
 		if (d->lights[i].type == HXR_LIGHT_RECT) s->features |= HXR_F_RECT;
 	if (s->arena.upload(d->textures, (size_t)d->num_textures, &V.textures)) return fail();

@@ -39,7 +39,8 @@ enum : unsigned {
 	HXR_F_GI = 16u,                                                                 // pathtrace() instead of raytrace()
 	HXR_F_EXTRA = 32u,                                                              // CSG geometry, glossy Reflection, anaglyph camera
 	HXR_F_RECT = 64u,                                                               // RectLight (every light is a PointLight otherwise)
-	HXR_F_ALL = 127u
+	HXR_F_REFRACT = 128u,                                                           // Refraction shader in the Whitted work list
+	HXR_F_ALL = 255u
 };
 
 // counters (COUNT builds only); order = hxr_counters
@@ -1440,12 +1441,14 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 								break;
 							}
 							case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
-								d3 out;
-								bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
-								if (ok && top < HXR_RAY_STACK) {
-									StackItem<glossy>& e = stack[top++];
-									e.r = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
-									if constexpr (glossy) e.left = 0;
+								if constexpr ((F & HXR_F_REFRACT) != 0) {
+									d3 out;
+									bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
+									if (ok && top < HXR_RAY_STACK) {
+										StackItem<glossy>& e = stack[top++];
+										e.r = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
+										if constexpr (glossy) e.left = 0;
+									}
 								}
 								break;
 							}

@@ -45,6 +45,8 @@ DETERMINISTIC = [
     ("meshes.hexray", dict(width=320, height=240), dict(mode=hx.MODE_AUTO), EXACT_COUNTERS),              # config 3a, adaptive AA as shipped
     ("heightfield.hexray", dict(width=320, height=180), dict(mode=hx.MODE_AUTO), ("camera_samples", "hf_calls", "shadow_queries")),   # config 4a
     ("smallpt.hexray", dict(width=160, height=120, gi=False), dict(mode=hx.MODE_SINGLE), EXACT_COUNTERS),   # spheres + rect light, Whitted
+    # the heart in glass (Layered: refraction + Fresnel-weighted reflection): the mesh variant WITH the Refraction shader
+    ("meshes.hexray", dict(width=240, height=180, want_aa=False, extra="Node heartNode {\nshader glass\n}\n"), dict(mode=hx.MODE_SINGLE), EXACT_COUNTERS),
 ]
 
 
