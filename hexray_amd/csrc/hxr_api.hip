@@ -16,16 +16,26 @@
 #include "hxr_accel.h"
 
 // compiled in hxr_kernels_mesh.hip (own scheduling flags)
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 
 
 namespace {
@@ -344,8 +354,14 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		int grid = grid_for(L.num_chunks);
 		const HxrSceneDev& V = s->host_view;
 #define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                     \
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, \
-	                   V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L)
+	do {                                                                                                                                                     \
+		if (L.mode == 1)                                                                                                                                     \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes,         \
+			                   V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L);          \
+		else                                                                                                                                                 \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, -1>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes,        \
+			                   V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L);          \
+	} while (0)
 #define HXR_LAUNCH_F(FEAT, WAVES)                                                         \
 	do {                                                                                  \
 		if (counters) HXR_LAUNCH(true, FEAT, WAVES); else HXR_LAUNCH(false, FEAT, WAVES); \

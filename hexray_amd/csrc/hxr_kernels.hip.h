@@ -1592,7 +1592,8 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // needs the latency hiding more than the registers) -- mesh-only Whitted, and the catch-all variants on scenes
 // with meshes (12 % faster than at 2); the heightfield marcher and the sphere path tracer keep more per-lane
 // state alive and are 16 % / 21 % faster at 2 (256 VGPRs, almost nothing spilled).
-template <bool COUNT, unsigned F, int W>
+// M: the render mode when known at compile time (1 = Monte-Carlo, the throughput mode), -1 = HxrLaunch::mode at run time
+template <bool COUNT, unsigned F, int W, int M>
 __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
     const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
     const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
@@ -1625,12 +1626,13 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	__shared__ unsigned long long lds_clock[HXR_BLOCK / 64][PH_NUM + 1];
 	tl.attach(lds_clock[wave]);
 #endif
+	const int mode_ = M >= 0 ? M : P.mode;
 	const int spp = P.spp;
 	const int lanes_per_pixel = spp < 64 ? spp : 64;          // samples of one pixel resident in the wave
 	const int ppc = P.pixels_per_chunk;                         // 64 / spp for spp <= 64, else 1
 	const int rounds = (spp + 63) / 64;
 	// pass 3 sizes itself from the device-side count of flagged pixels (no host round trip between the passes)
-	const uint32_t num_chunks = P.mode == 2 ? ((uint32_t)*P.aa_count + (uint32_t)ppc - 1u) / (uint32_t)ppc : P.num_chunks;
+	const uint32_t num_chunks = mode_ == 2 ? ((uint32_t)*P.aa_count + (uint32_t)ppc - 1u) / (uint32_t)ppc : P.num_chunks;
 	// Packet dispenser.  One device-scope counter saturates near 88 tickets/us (MI355X_MICROARCH.md, row
 	// "dequeue") -- 518,400 single-packet tickets of the headline frame would cost 6 ms by themselves -- so the
 	// packets are split into HXR_SHARDS contiguous ranges with a counter each (one per XCD under the
@@ -1643,7 +1645,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	// serves its lanes one after the other, so its duration grows with the number of live lanes -- up to 8 ms for one packet
 	// of the headline frame, which no other wave can help with.  Split four ways and started first, the same pixels finish
 	// in a quarter of the time while the cheap packets fill the machine.  The image does not depend on any of this.
-	const bool scheduled = P.sched_counts != nullptr && P.mode != 2;
+	const bool scheduled = P.sched_counts != nullptr && mode_ != 2;
 	const uint32_t listed_a = scheduled ? P.sched_counts[0] : 0u, listed_b = scheduled ? P.sched_counts[1] : 0u;
 	bool listed_left = listed_a + listed_b > 0;
 	for (;;) {
@@ -1692,7 +1694,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		// which pixel
 		int x = 0, y = 0;
 		uint32_t q = 0;
-		if (P.mode == 2) {        // AA taps: aa_list holds frame pixel numbers, 4 taps each
+		if (mode_ == 2) {        // AA taps: aa_list holds frame pixel numbers, 4 taps each
 			uint32_t e = chunk * (uint32_t)ppc + (uint32_t)slot;
 			live = live && e < (uint32_t)*P.aa_count;
 			if (live) { int pix = P.aa_list[e]; x = pix % P.W; y = pix / P.W; }
@@ -1714,13 +1716,13 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 				int s = sub + rd * 64;
 				if (s >= spp) break;
 				double sx = x, sy = y;
-				if (P.mode == 1) {          // renderWithMonteCarlo: x + randDouble(), y + randDouble() (src/main.cpp:373-375)
+				if (mode_ == 1) {          // renderWithMonteCarlo: x + randDouble(), y + randDouble() (src/main.cpp:373-375)
 					rc.sample = (uint32_t)s;
 					double jx, jy;
 					hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_PIXEL_JITTER), jx, jy);
 					sx = x + jx;
 					sy = y + jy;
-				} else if (P.mode == 2) {   // pass 3 taps 1..4 of AA_KERNEL; `x + 0.6f` is float arithmetic (src/main.cpp:255-261,336)
+				} else if (mode_ == 2) {   // pass 3 taps 1..4 of AA_KERNEL; `x + 0.6f` is float arithmetic (src/main.cpp:255-261,336)
 					const float kx[4] = {0.6f, 0.3f, 0.0f, 0.6f}, ky[4] = {0.0f, 0.3f, 0.6f, 0.6f};
 					rc.sample = (uint32_t)(s + 1);
 					sx = (double)((float)x + kx[s]);
@@ -1755,12 +1757,12 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		// Combine the samples of each pixel in sample order (the reference adds them one by one, src/main.cpp:372-377).
 		// The lanes of a pixel are adjacent, so the running sum walks through them with one wave-shift per sample:
 		// after step k the lane of sample k holds ((s0 + s1) + ...) + sk.  No LDS round trip, all lanes in lockstep.
-		const bool in_tile = P.mode != 2 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+		const bool in_tile = mode_ != 2 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
 		float* dst = nullptr;
 		f3 acc = mkf(0, 0, 0);
 		if (live && (sub == 0 || sub == lanes_per_pixel - 1)) {
 			dst = in_tile ? out_pixel(P, q, x, y) : (float*)((char*)P.out + (size_t)y * P.out_stride) + (size_t)x * 3;
-			if (P.mode == 2 && sub == 0) acc = mkf(dst[0], dst[1], dst[2]);   // pass 3 adds onto the pass-1 colour
+			if (mode_ == 2 && sub == 0) acc = mkf(dst[0], dst[1], dst[2]);   // pass 3 adds onto the pass-1 colour
 		}
 		acc = acc + sum;
 		for (int k = 1; k < lanes_per_pixel; k++) {
@@ -1768,8 +1770,8 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			if (sub == k) acc = left + sum;
 		}
 		if (live && sub == lanes_per_pixel - 1) {
-			if (P.mode == 1) acc = acc * (1.0f / spp);
-			else if (P.mode == 2) acc = acc * (1.0f / 5);
+			if (mode_ == 1) acc = acc * (1.0f / spp);
+			else if (mode_ == 2) acc = acc * (1.0f / 5);
 			dst[0] = acc.x;
 			dst[1] = acc.y;
 			dst[2] = acc.z;
