@@ -767,20 +767,31 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	}
 	if (s->arena.upload(nodes.data(), nodes.size(), &V.nodes)) return fail();
 	if (s->arena.upload(d->geometries, (size_t)d->num_geometries, &V.geometries)) return fail();
-	{   // Refraction / glossy Reflection count only where a node's shader tree reaches them (scene files define shaders they do not use)
+	{   // Refraction, glossy Reflection, Fresnel and Bumps textures count only where a node reaches them through its shader tree
+		// or bump map (scene files define materials they do not use)
 		std::vector<char> seen((size_t)d->num_shaders, 0);
 		std::vector<int> todo;
-		for (int64_t i = 0; i < d->num_nodes; i++) todo.push_back(d->nodes[i].shader);
+		auto texture_used = [&](int t) {
+			if (t >= 0 && t < d->num_textures && (d->textures[t].type == HXR_TEX_FRESNEL || d->textures[t].type == HXR_TEX_BUMPS)) s->features |= HXR_F_REFRACT;
+		};
+		for (int64_t i = 0; i < d->num_nodes; i++) {
+			todo.push_back(d->nodes[i].shader);
+			texture_used(d->nodes[i].bump);
+		}
 		while (!todo.empty()) {
 			int sh = todo.back();
 			todo.pop_back();
 			if (sh < 0 || sh >= d->num_shaders || seen[(size_t)sh]) continue;
 			seen[(size_t)sh] = 1;
 			const hxr_shader& S = d->shaders[sh];
+			texture_used(S.texture);
 			if (S.type == HXR_SHADER_REFRACTION) s->features |= HXR_F_REFRACT;
 			if (S.type == HXR_SHADER_REFLECTION && S.glossiness < 1.0f) s->features |= HXR_F_EXTRA;
 			if (S.type == HXR_SHADER_LAYERED)
-				for (int k = 0; k < S.num_layers; k++) todo.push_back(d->layers[S.first_layer + k].shader);
+				for (int k = 0; k < S.num_layers; k++) {
+					todo.push_back(d->layers[S.first_layer + k].shader);
+					texture_used(d->layers[S.first_layer + k].texture);
+				}
 		}
 	}
 	for (int64_t i = 0; i < d->num_lights; i++)

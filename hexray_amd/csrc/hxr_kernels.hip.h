@@ -39,7 +39,7 @@ enum : unsigned {
 	HXR_F_GI = 16u,                                                                 // pathtrace() instead of raytrace()
 	HXR_F_EXTRA = 32u,                                                              // CSG geometry, glossy Reflection, anaglyph camera
 	HXR_F_RECT = 64u,                                                               // RectLight (every light is a PointLight otherwise)
-	HXR_F_REFRACT = 128u,                                                           // Refraction shader in the Whitted work list
+	HXR_F_REFRACT = 128u,                                                           // glass and water: Refraction shader in the Whitted work list, Fresnel and Bumps textures
 	HXR_F_ALL = 255u
 };
 
@@ -931,7 +931,7 @@ HXR_DEV f3 bitmap_bilinear(const HxrBitmapDev& b, float x, float y)   // Bitmap:
 	       ldf(t + ((size_t)ty1 * w + tx) * 3) * ((1.0f - p) * q) + ldf(t + ((size_t)ty1 * w + tx1) * 3) * (p * q);
 }
 
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 HXR_DEVX f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& sf, Tally<COUNT>& tl)
 {
 	const hxr_texture& t = S.textures[ti];
@@ -950,7 +950,7 @@ HXR_DEVX f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& 
 			tl.add(HC_TEX);
 			return bitmap_bilinear(b, u, v);
 		}
-		case HXR_TEX_FRESNEL: {   // src/shading.cpp:326-343, float arithmetic
+		case HXR_TEX_FRESNEL: if constexpr ((F & HXR_F_REFRACT) != 0) {   // src/shading.cpp:326-343, float arithmetic
 			float eta = (float)t.ior;
 			float ndi = (float)dot(dir, sf.norm);
 			if (ndi > 0) eta = 1 / eta; else ndi = -ndi;
@@ -959,12 +959,12 @@ HXR_DEVX f3 texture_sample(const HxrSceneDev& S, int ti, d3 dir, const Surface& 
 			float x = 1 - ndi;
 			float fr = f + (1 - f) * powf(x, 5.0f);
 			return mkf(fr, fr, fr);
-		}
+		} else return mkf(0, 0, 0);
 		default: return mkf(0, 0, 0);
 	}
 }
 
-template <bool COUNT>
+template <bool COUNT, unsigned F>
 HXR_DEVX void texture_bump(const HxrSceneDev& S, int ti, Surface& sf, Tally<COUNT>& tl)
 {
 	const hxr_texture& t = S.textures[ti];
@@ -976,7 +976,7 @@ HXR_DEVX void texture_bump(const HxrSceneDev& S, int ti, Surface& sf, Tally<COUN
 		f3 bump = bitmap_bilinear(b, x, y);
 		float dx = (float)(bump.x * t.strength), dy = (float)(bump.y * t.strength);
 		sf.norm = unit(sf.norm + (sf.dNdx * (double)dx + sf.dNdy * (double)dy));
-	} else if (t.type == HXR_TEX_BUMPS) {   // Bumps::modifyNormal, src/shading.cpp:363-377
+	} else if ((F & HXR_F_REFRACT) != 0 && t.type == HXR_TEX_BUMPS) {   // Bumps::modifyNormal, src/shading.cpp:363-377
 		float strength = (float)t.strength;
 		if (strength > 0) {
 			const float fx[3] = {0.5f, 1.21f, 1.9f}, fz[3] = {0.4f, 1.13f, 1.81f}, amp[3] = {0.1f, 0.08f, 0.05f};
@@ -1273,7 +1273,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 					Surface sf;
 					surface_of<COUNT, F>(S, u_node, qo, qd, bg, bw, sf, tl);
 					int bump = S.nodes[u_node].bump;
-					if (bump >= 0) texture_bump<COUNT>(S, bump, sf, tl);
+					if (bump >= 0) texture_bump<COUNT, F>(S, bump, sf, tl);
 					hp.ip = sf.ip;
 					hp.norm = sf.norm;
 					hp.u = sf.u;
@@ -1312,7 +1312,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 				else {
 					if (in_lights) {   // first visit of this vertex: try the explicit light sample
 						in_lights = false;
-						if (diffuse) base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
+						if (diffuse) base = sh.texture >= 0 ? texture_sample<COUNT, F>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
 						if (S.num_lights > 0) {
 							HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_PICK);
 							li = (int)hxr_below(pick.w0, (uint32_t)S.num_lights);
@@ -1413,7 +1413,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 							case HXR_SHADER_PHONG:
 								cur_shader = u_si;
 								cur_w = w;
-								base = sh.texture >= 0 ? texture_sample<COUNT>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
+								base = sh.texture >= 0 ? texture_sample<COUNT, F>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
 								direct = mkf(0, 0, 0);
 								sum = mkf(0, 0, 0);
 								li = 0;
@@ -1456,7 +1456,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 								f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
 								for (int i = sh.num_layers - 1; i >= 0; i--) {
 									const hxr_layer& Ly = S.layers[sh.first_layer + i];
-									f3 blend = Ly.texture >= 0 ? texture_sample<COUNT>(S, Ly.texture, cur.d, sfl, tl) : ldf(Ly.blend);
+									f3 blend = Ly.texture >= 0 ? texture_sample<COUNT, F>(S, Ly.texture, cur.d, sfl, tl) : ldf(Ly.blend);
 									if (stop < HXR_SHADER_STACK) {
 										sh_stack[stop] = Ly.shader;
 										w_stack[stop++] = (w * blend) * rem;
