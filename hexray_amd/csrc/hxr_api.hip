@@ -18,8 +18,6 @@
 // compiled in hxr_kernels_mesh.hip (own scheduling flags)
 extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
 extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
@@ -366,6 +364,11 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 	do {                                                                                  \
 		if (counters) HXR_LAUNCH(true, FEAT, WAVES); else HXR_LAUNCH(false, FEAT, WAVES); \
 	} while (0)
+// a variant that exists only uninstrumented: the counted frames (tests, bench counters) run its superset COUNTED_FEAT
+#define HXR_LAUNCH_F2(FEAT, COUNTED_FEAT, WAVES)                                                  \
+	do {                                                                                          \
+		if (counters) HXR_LAUNCH(true, COUNTED_FEAT, WAVES); else HXR_LAUNCH(false, FEAT, WAVES); \
+	} while (0)
 		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h);
 		// occupancy target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel)
 		unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
@@ -373,7 +376,7 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
 		const bool rect = (s->features & HXR_F_RECT) != 0;   // the specialised Whitted variants know PointLights only
 		const bool refr = (s->features & HXR_F_REFRACT) != 0;
-		if (!gi && !rect && !refr && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH, 3);
+		if (!gi && !rect && !refr && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F2(HXR_F_MESH, HXR_F_MESH | HXR_F_REFRACT, 3);
 		else if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, 3);
 		else if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD | HXR_F_REFRACT, 2);
 		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 2);
@@ -382,6 +385,7 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 		else if (gi) HXR_LAUNCH_F(HXR_F_ALL, 2);
 		else if (meshes) HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3);
 		else HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 2);
+#undef HXR_LAUNCH_F2
 #undef HXR_LAUNCH_F
 #undef HXR_LAUNCH
 		HIP_TRY(hipGetLastError());
