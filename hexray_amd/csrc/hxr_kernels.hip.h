@@ -1575,7 +1575,9 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // ------------------------------------------------------------------------------------------------
 // the render kernel: persistent wavefronts, one ray packet (64 camera samples) per dispenser ticket
 // ------------------------------------------------------------------------------------------------
+#ifndef HXR_BLOCK
 #define HXR_BLOCK 256
+#endif
 #define HXR_SCHED_WHOLE 0x80000000u   // schedule item flag: the whole chunk that starts at this pixel
 #define HXR_SCHED_PART 0x40000000u    // schedule item flag: bits 22..29 = which HXR_PART_LANES samples, bits 0..21 = part slot
 #define HXR_PART_LANES 4
