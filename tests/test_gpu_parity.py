@@ -273,7 +273,11 @@ def test_sah_tree_statistics_and_errors(gpu):
 def test_adaptive_schedule_does_not_change_the_frame(gpu):
     """From the second frame on the packets are handed out in another order and the expensive ones one pixel at a time
     (feedback from the previous frame's per-chunk clocks): every frame must stay bit-identical, with and without it."""
-    for ov, fp in ((hx.overlay_text(640, 360, dof=True, num_samples=16), dict()), (hx.overlay_text(640, 360, want_aa=False), dict(mode=hx.MODE_SINGLE))):
+    cases = [(hx.overlay_text(640, 360, dof=True, num_samples=16), dict()), (hx.overlay_text(640, 360, want_aa=False), dict(mode=hx.MODE_SINGLE))]
+    # other pixel / packet shapes: 8 lanes per pixel (two parts), 32 (eight), a whole wave per pixel, and a sample count that
+    # cannot be split into parts
+    cases += [(hx.overlay_text(480, 270, dof=True, num_samples=n), dict()) for n in (8, 32, 64, 20)]
+    for ov, fp in cases:
         hs = hx.HostScene(scene_path("meshes.hexray"), ov)
         plain = hx.DeviceScene(hs, adaptive_schedule=False).render(hx.frame_params(**fp))
         ds = hx.DeviceScene(hs)
@@ -304,3 +308,30 @@ def test_anaglyph_camera_matches_oracle(gpu, scene, ov, fp):
     hs = hx.HostScene(scene_path(scene), ov.replace("stereoSeparation 0.3", "stereoSeparation 0").replace("stereoSeparation 2", "stereoSeparation 0"))
     flat = hx.DeviceScene(hs).render(hx.frame_params(**fp))
     assert rms(g, flat).mean() > 1e-3   # and the pair really is rendered
+
+
+def test_sharded_frames_with_a_cost_map(gpu):
+    """Eight-way shard of a frame large enough for the adaptive schedule (8x8 tiles as in bench.py): each rank renders its
+    share three times -- the second and third from the cost map of the one before -- and every assembled frame is the
+    single-GPU frame bit for bit."""
+    import torch
+    from hexray_amd.distributed import padded_tiles_per_rank
+    W, H, world, tile = 960, 540, 8, 8
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(W, H, dof=True, num_samples=16))
+    whole = hx.DeviceScene(hs, adaptive_schedule=False).render(hx.frame_params())
+    scenes = [hx.DeviceScene(hs) for _ in range(world)]          # one scene handle per rank, as in one process per GPU
+    slots = padded_tiles_per_rank(W, H, tile, world)
+    stream = torch.cuda.current_stream().cuda_stream
+    for frame_no in range(3):
+        parts = []
+        for rank in range(world):
+            p = hx.frame_params(tile_size=tile, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
+            buf = torch.zeros(slots * tile * tile * 3, dtype=torch.float32, device="cuda")
+            scenes[rank].render_device(p, buf.data_ptr(), 0, stream)
+            parts.append(buf)
+        gathered = torch.cat(parts)
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        p0 = hx.frame_params(tile_size=tile, shard_rank=0, shard_count=world, layout=hx.LAYOUT_TILES)
+        scenes[0].assemble_frame(p0, gathered.data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), whole), frame_no
