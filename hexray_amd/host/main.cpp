@@ -17,7 +17,8 @@ static void usage()
 {
 	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
 	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc] [--seed S] [--device D]\n"
-	       "              [--frames N] [--out frame.bmp|frame.raw] [--counters]\n");
+	       "              [--frames N] [--out frame.bmp|frame.raw] [--counters] [--accel reference|sah]\n"
+	       "              [--no-adaptive-schedule]\n");
 }
 
 int main(int argc, char** argv)
@@ -28,6 +29,9 @@ int main(int argc, char** argv)
 	memset(&fp, 0, sizeof fp);
 	fp.rng_seed = 5489;
 	int device = 0, frames = 1;
+	hxr_scene_options opt;
+	memset(&opt, 0, sizeof opt);
+	opt.struct_size = sizeof opt;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -46,6 +50,8 @@ int main(int argc, char** argv)
 		else if (a == "--frames") frames = atoi(next());
 		else if (a == "--out") out = next();
 		else if (a == "--counters") fp.collect_counters = 1;
+		else if (a == "--accel") { std::string v = next(); opt.accel = v == "sah" ? HXR_ACCEL_SAH : HXR_ACCEL_REFERENCE; }
+		else if (a == "--no-adaptive-schedule") opt.no_adaptive_schedule = 1;
 		else if (a == "-h" || a == "--help") { usage(); return 0; }
 		else if (!a.empty() && a[0] != '-') scene = a;
 		else { usage(); return 2; }
@@ -73,8 +79,8 @@ int main(int argc, char** argv)
 	}
 	if (hxr_init(device)) { printf("GPU init failed: %s\n", hxr_last_error()); return 1; }
 	auto t0 = std::chrono::steady_clock::now();
-	hxr_scene* ds = hxr_scene_create(d);
-	if (!ds) { printf("hxr_scene_create failed: %s\n", hxr_last_error()); return 1; }
+	hxr_scene* ds = hxr_scene_create_ex(d, &opt);
+	if (!ds) { printf("hxr_scene_create_ex failed: %s\n", hxr_last_error()); return 1; }
 	int W = d->settings.frame_width, H = d->settings.frame_height;
 	std::vector<float> vfb((size_t)W * H * 3);
 	int rc = 0;
