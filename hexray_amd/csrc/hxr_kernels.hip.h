@@ -438,8 +438,7 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 			atomicAdd(S.dev_stats + 1, (unsigned long long)(count < coop ? count : coop));
 			atomicAdd(S.dev_stats + 2, 1ull);
 			atomicAdd(S.dev_stats + 3, (unsigned long long)k);
-			if (k <= 4) atomicAdd(S.dev_stats + 4, (unsigned long long)count);
-			if (k <= 16) atomicAdd(S.dev_stats + 5, (unsigned long long)count);
+			if (count == 0) atomicAdd(S.dev_stats + 4, 1ull);   // visits of EMPTY leaves
 		}
 	}
 #endif
@@ -535,6 +534,9 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		const int ac = R.axis_count;
 		const int axis = ac & 3;
 		bool descended = false;
+#ifdef HXR_LEAF_STATS
+		if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) atomicAdd(S.dev_stats + 5, 1ull);   // walk steps
+#endif
 		if (axis == HXR_KD_LEAF) {
 			bool here = leaf_query<COUNT>(S, M, R.first, ac >> 2, (mask & me) != 0, cb, o, d, nd, g, st, tl);
 			found = found || here;

@@ -13,5 +13,5 @@ for wl in sys.argv[1:] or ["meshes16"]:
         ds = hx.DeviceScene(hs, accel=accel, adaptive_schedule=False)
         ds.render(hx.frame_params(tile_size=32))
         r = list(ds.counters_raw().reserved_)
-        print("%s accel %d: leaf visits %d, triangle iterations (wave level) %d = %.1f per visit, lanes per visit %.1f; iterations in visits with <= 4 lanes %.1f%%, <= 16 lanes %.1f%%; "
-              "cost if every visit took min(count, 2 + 1.5 lanes): %.1f%% of now" % (wl, accel, r[2], r[0], r[0] / max(1, r[2]), r[3] / max(1, r[2]), 100.0 * r[4] / max(1, r[0]), 100.0 * r[5] / max(1, r[0]), 100.0 * r[1] / max(1, r[0])), flush=True)
+        print("%s accel %d: leaf visits %d, triangle iterations (wave level) %d = %.1f per visit, lanes per visit %.1f; walk steps %d of which empty-leaf visits %d (%.1f%%); "
+              "cost if every visit took min(count, 2 + 1.5 lanes): %.1f%% of now" % (wl, accel, r[2], r[0], r[0] / max(1, r[2]), r[3] / max(1, r[2]), r[5], r[4], 100.0 * r[4] / max(1, r[5]), 100.0 * r[1] / max(1, r[0])), flush=True)
