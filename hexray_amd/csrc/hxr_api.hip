@@ -114,6 +114,7 @@ struct hxr_scene {
 	unsigned long long* d_sched_ctl = nullptr;                         // [0] total cost, then as uint32: [2] listed from the front, [3] from the back, [4] part slots, [5] ticket
 	struct SchedKey { int W, H, mode, spp, tile, rank, count; uint32_t chunks; } sched_key = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool sched_history = false;
+	bool aa_cost_aware = false;         // the last frame was an adaptive-AA frame whose flagged list has a back part
 	uint8_t* d_lut = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
@@ -485,6 +486,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (want_counter_buffer) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
 	s->counters_valid = want_counter_buffer;
 	s->timed = false;
+	s->aa_cost_aware = false;
 	HxrLaunch L;
 	fill_launch(s, p, L);
 	L.counters = want_counter_buffer ? s->d_counters : nullptr;
@@ -550,11 +552,38 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	L.out_stride = fstride;
 	L.out_tiles = 0;
 	L.work_counter = s->d_work;
+	// pass 1 records what its 64-pixel chunks cost (same machinery as the adaptive schedule, nothing listed): pass 3 of THIS
+	// frame starts with the flagged pixels of the expensive chunks, one pixel per packet
+	const uint32_t list_capacity = tile_pixels + 64u;
+	const bool cost_aware = s->adaptive && L.num_chunks >= 1024 && !getenv("HXR_AA_NO_COST");
+	s->aa_cost_aware = cost_aware;
+	if (cost_aware) {
+		rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)L.num_chunks * sizeof(uint32_t));
+		if (!rc) rc = ensure((void**)&s->d_sched_flags, &s->sched_flags_cap, (size_t)L.num_chunks);
+		if (rc) return rc;
+		if (!s->d_sched_ctl) HIP_TRY(hipMalloc((void**)&s->d_sched_ctl, 64));
+		HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
+		HIP_TRY(hipMemsetAsync(s->d_sched_cost, 0, (size_t)L.num_chunks * sizeof(uint32_t), st));
+		HIP_TRY(hipMemsetAsync(s->d_sched_flags, 0, (size_t)L.num_chunks, st));
+		L.sched_cost = s->d_sched_cost;
+		L.sched_flags = s->d_sched_flags;
+		L.sched_counts = (const uint32_t*)s->d_sched_ctl + 6;   // two zeros: nothing is listed in pass 1
+		L.sched_ticket = (uint32_t*)s->d_sched_ctl + 8;
+		s->sched_history = false;                                // the Monte-Carlo cost map, if any, is gone
+	}
 	rc = launch_render(s, L, counters, st, true);
 	if (rc) return rc;
 	if (tile_pixels) {
+		if (cost_aware) {
+			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 1024u);
+			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
+		}
+		uint32_t heavy_x = 16;   // frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list)
+		if (const char* e = getenv("HXR_AA_HEAVY_X")) heavy_x = (uint32_t)atoi(e);   // developer aid
 		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)g_num_cu * 8u);
-		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512));
+		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512),
+		                   cost_aware ? (const uint32_t*)s->d_sched_cost : (const uint32_t*)nullptr, (const unsigned long long*)s->d_sched_ctl, L.num_chunks,
+		                   cost_aware ? (uint32_t*)s->d_sched_ctl + 3 : (uint32_t*)nullptr, list_capacity, heavy_x);
 		HIP_TRY(hipGetLastError());
 	}
 	// pass 3: the flagged-pixel count stays on the device; launch enough waves for the worst case and let them drain
@@ -567,6 +596,15 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (const char* e = getenv("HXR_AA_PPC")) L3.pixels_per_chunk = atoi(e);   // developer aid
 	L3.num_extra_pixels = 0;
 	L3.aa_list = s->d_aa_list;
+	L3.sched_cost = nullptr;
+	L3.sched_flags = nullptr;
+	L3.sched_counts = nullptr;
+	if (cost_aware) {   // the back of the flagged list, single pixels, first
+		L3.sched_items = (const uint32_t*)s->d_aa_list;
+		L3.sched_capacity = list_capacity;
+		L3.sched_counts = (const uint32_t*)s->d_sched_ctl + 2;   // [2] stays 0 (nothing from the front), [3] = pixels at the back
+		L3.sched_ticket = (uint32_t*)s->d_sched_ctl + 5;
+	}
 	L3.num_chunks = (tile_pixels + (uint32_t)L3.pixels_per_chunk - 1u) / (uint32_t)L3.pixels_per_chunk;
 	L3.work_counter = s->d_work + 256;
 	rc = launch_render(s, L3, counters, st, false);
@@ -994,9 +1032,10 @@ int hxr_get_counters(const hxr_scene* s, hxr_counters* out)
 	for (int i = 0; i < HC_NUM; i++) o[i] = raw[i];
 	static_assert(sizeof(hxr_counters) >= (HC_NUM + PH_NUM) * sizeof(uint64_t), "phase clocks must fit the reserved words");
 	for (int i = 0; i < PH_NUM; i++) out->reserved_[i] = raw[HC_NUM + i];   // zero unless built with -DHXR_PHASE_TIMERS
-	uint32_t flagged = 0;
+	uint32_t flagged = 0, flagged_heavy = 0;
 	HIP_TRY(hipMemcpy(&flagged, s->d_work + 512, sizeof flagged, hipMemcpyDeviceToHost));
-	out->aa_pixels = flagged;
+	if (s->aa_cost_aware) HIP_TRY(hipMemcpy(&flagged_heavy, (uint32_t*)s->d_sched_ctl + 3, sizeof flagged_heavy, hipMemcpyDeviceToHost));   // the back of the list
+	out->aa_pixels = (uint64_t)flagged + flagged_heavy;
 	return 0;
 }
 

@@ -1649,8 +1649,8 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	// serves its lanes one after the other, so its duration grows with the number of live lanes -- up to 8 ms for one packet
 	// of the headline frame, which no other wave can help with.  Split four ways and started first, the same pixels finish
 	// in a quarter of the time while the cheap packets fill the machine.  The image does not depend on any of this.
-	const bool scheduled = P.sched_counts != nullptr && mode_ != 2;
-	const uint32_t listed_a = scheduled ? P.sched_counts[0] : 0u, listed_b = scheduled ? P.sched_counts[1] : 0u;
+	const bool scheduled = P.sched_counts != nullptr && mode_ != 2;   // pass 3 only takes a list of single pixels (see the AA host path)
+	const uint32_t listed_a = P.sched_counts ? P.sched_counts[0] : 0u, listed_b = P.sched_counts ? P.sched_counts[1] : 0u;
 	bool listed_left = listed_a + listed_b > 0;
 	for (;;) {
 		uint32_t single_pixel = 0xffffffffu;   // != ~0: this packet renders only that pixel
@@ -1700,8 +1700,8 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		uint32_t q = 0;
 		if (mode_ == 2) {        // AA taps: aa_list holds frame pixel numbers, 4 taps each
 			uint32_t e = chunk * (uint32_t)ppc + (uint32_t)slot;
-			live = live && e < (uint32_t)*P.aa_count;
-			if (live) { int pix = P.aa_list[e]; x = pix % P.W; y = pix / P.W; }
+			if (!single) live = live && e < (uint32_t)*P.aa_count;
+			if (live) { int pix = single ? (int)single_pixel : P.aa_list[e]; x = pix % P.W; y = pix / P.W; }   // a listed item IS the frame pixel
 		} else {
 			q = single ? single_pixel : chunk * (uint32_t)ppc + (uint32_t)slot;
 			uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
@@ -1907,9 +1907,14 @@ __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
 // detectAApixels, src/main.cpp:192-222: a pixel needs AA when any channel differs from any of its 8
 // neighbours by more than 0.075 after clamping to 1.  Flagged pixels are appended to a compact list with
 // one atomic per wave (ballot + prefix count).
+// `cost` (may be null): what the 64-pixel chunks of pass 1 took; flagged pixels of chunks above `heavy_x` times the mean go to the BACK of
+// the list (`heavy_count` of them), to be traced first and one pixel per packet by pass 3 -- the flagged set is small and made
+// of the most expensive pixels of the frame, so a few 32-lane packets of them would otherwise decide when pass 3 ends.
 __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, const float* __restrict__ frame, size_t stride, int32_t* list,
-                                                                   int32_t* count)
+                                                                   int32_t* count, const uint32_t* __restrict__ cost, const unsigned long long* total,
+                                                                   uint32_t cost_chunks, uint32_t* heavy_count, uint32_t capacity, uint32_t heavy_x)
 {
+	const unsigned long long heavy_above = cost ? (unsigned long long)heavy_x * (*total / (cost_chunks ? cost_chunks : 1u)) : ~0ull;
 	uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
 	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < ((tile_pixels + 63u) & ~63u); q += gridDim.x * blockDim.x) {
 		int x, y;
@@ -1926,12 +1931,16 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, c
 						if (fabsf(fminf(1.0f, me[c]) - fminf(1.0f, nb[c])) > 0.075f) { need = true; break; }
 				}
 		}
-		unsigned long long mask = hxr_ballot(need);
+		const bool heavy = need && cost && (unsigned long long)cost[q >> 6] > heavy_above;   // pass-1 chunks are 64 consecutive pixel numbers
+		unsigned long long mask = hxr_ballot(need && !heavy), hmask = hxr_ballot(heavy);
 		int lane = threadIdx.x & 63;
-		int base = 0;
+		int base = 0, hbase = 0;
 		if (lane == 0 && mask) base = atomicAdd(count, __popcll(mask));
+		if (lane == 0 && hmask) hbase = (int)atomicAdd(heavy_count, (uint32_t)__popcll(hmask));
 		base = __shfl(base, 0, 64);
-		if (need) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = y * P.W + x;
+		hbase = __shfl(hbase, 0, 64);
+		if (need && !heavy) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = y * P.W + x;
+		if (heavy) list[capacity - 1u - (uint32_t)(hbase + __popcll(hmask & ((1ull << lane) - 1ull)))] = y * P.W + x;
 	}
 }
 
