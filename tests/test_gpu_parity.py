@@ -335,3 +335,32 @@ def test_sharded_frames_with_a_cost_map(gpu):
         scenes[0].assemble_frame(p0, gathered.data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, stream)
         torch.cuda.synchronize()
         assert np.array_equal(frame.cpu().numpy(), whole), frame_no
+
+
+def test_cost_aware_aa_pass_is_invisible(gpu):
+    """Adaptive AA on a frame large enough for the cost-aware pass 3 (flagged pixels of expensive chunks first, one pixel per
+    packet): same frame and same number of flagged pixels as with the plain list, whole and in four shards."""
+    import torch
+    from hexray_amd.distributed import padded_tiles_per_rank
+    W, H, world, tile = 960, 540, 4, 16
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(W, H))
+    fp = dict(mode=hx.MODE_ADAPTIVE_AA)
+    plain_scene = hx.DeviceScene(hs, adaptive_schedule=False)
+    plain = plain_scene.render(hx.frame_params(collect_counters=True, **fp))
+    ds = hx.DeviceScene(hs)
+    whole = ds.render(hx.frame_params(collect_counters=True, **fp))
+    assert np.array_equal(whole, plain)
+    assert ds.counters()["aa_pixels"] == plain_scene.counters()["aa_pixels"] > 1000
+    slots = padded_tiles_per_rank(W, H, tile, world)
+    st = torch.cuda.current_stream().cuda_stream
+    parts = []
+    for rank in range(world):
+        p = hx.frame_params(tile_size=tile, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES, **fp)
+        buf = torch.zeros(slots * tile * tile * 3, dtype=torch.float32, device="cuda")
+        ds.render_device(p, buf.data_ptr(), 0, st)
+        parts.append(buf)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    p0 = hx.frame_params(tile_size=tile, shard_rank=0, shard_count=world, layout=hx.LAYOUT_TILES, **fp)
+    ds.assemble_frame(p0, torch.cat(parts).data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), plain)
