@@ -20,14 +20,15 @@ if [ "$what" = all ] || [ "$what" = oracle ]; then
 	make -s -C oracle liboracle.so
 fi
 if [ "$what" = all ] || [ "$what" = hip ]; then
-	HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Ihexray_amd/csrc"
 	mkdir -p build
-	# the mesh-only Whitted kernels take another instruction-scheduling strategy (see hxr_kernels_mesh.hip); the two
-	# objects are compiled side by side
-	hipcc $HIPFLAGS -mllvm -amdgpu-sched-strategy=max-ilp -c -o build/hxr_kernels_mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
-	hipcc $HIPFLAGS -c -o build/hxr_api.o hexray_amd/csrc/hxr_api.hip
+	# the variants of the render kernel are spread over three translation units, each with the flags measured best for it
+	# (see the headers of hxr_kernels_mesh.hip / hxr_kernels_heightfield.hip); the objects are compiled side by side
+	HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -Ihexray_amd/csrc"
+	hipcc $HIPFLAGS -O2 -mllvm -amdgpu-sched-strategy=max-ilp -c -o build/hxr_kernels_mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
+	hipcc $HIPFLAGS -O2 -c -o build/hxr_kernels_heightfield.o hexray_amd/csrc/hxr_kernels_heightfield.hip &
+	hipcc $HIPFLAGS -O3 -c -o build/hxr_api.o hexray_amd/csrc/hxr_api.hip
 	wait
-	hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip.so build/hxr_api.o build/hxr_kernels_mesh.o
+	hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip.so build/hxr_api.o build/hxr_kernels_mesh.o build/hxr_kernels_heightfield.o
 fi
 if [ "$what" = all ] || [ "$what" = cli ]; then
 	g++ $CXXFLAGS -o hexray_amd/bin/hexray hexray_amd/host/main.cpp -Lhexray_amd/lib -lhexray_host -lhexray_hip \

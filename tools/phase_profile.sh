@@ -7,7 +7,7 @@ lib1=hexray_amd/lib/libhexray_hip_timers1.so; lib2=hexray_amd/lib/libhexray_hip_
 if [ "$1" = build ] || [ ! -f $lib1 ] || [ ! -f $lib2 ] || [ ! -f $lib3 ]; then
 	for set in 1 2 3; do
 		hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DHXR_PHASE_TIMERS -DHXR_PHASE_SET=$set -Iinclude -Ihexray_amd/csrc \
-			-o hexray_amd/lib/libhexray_hip_timers$set.so hexray_amd/csrc/hxr_api.hip hexray_amd/csrc/hxr_kernels_mesh.hip
+			-o hexray_amd/lib/libhexray_hip_timers$set.so hexray_amd/csrc/hxr_api.hip hexray_amd/csrc/hxr_kernels_mesh.hip hexray_amd/csrc/hxr_kernels_heightfield.hip
 	done
 	[ "$1" = build ] && exit 0
 fi
