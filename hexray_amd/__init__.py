@@ -51,7 +51,18 @@ ACCEL_REFERENCE, ACCEL_SAH = 0, 1
 class SceneOptions(ctypes.Structure):
     """hxr_scene_options (include/hexray_hip.h)."""
 
-    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32), ("no_adaptive_schedule", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32), ("no_adaptive_schedule", ctypes.c_int32), ("deferred_rays", ctypes.c_int32)]
+
+
+class FrameTiming(ctypes.Structure):
+    """hxr_frame_timing (include/hexray_hip.h)."""
+
+    _fields_ = [("total_ms", c_double), ("render_ms", c_double), ("continue_ms", c_double), ("resolve_ms", c_double),
+                ("deferred_rays", c_uint64), ("reserved_", c_uint64 * 3)]
+
+    def as_dict(self):
+        return {"total_ms": self.total_ms, "render_ms": self.render_ms, "continue_ms": self.continue_ms, "resolve_ms": self.resolve_ms,
+                "deferred_rays": int(self.deferred_rays)}
 
 
 class Counters(ctypes.Structure):
@@ -251,6 +262,7 @@ def hip_lib():
         lib.hxr_get_counters.argtypes = [c_void_p, POINTER(Counters)]
         lib.hxr_last_kernel_ms.restype = c_double
         lib.hxr_last_kernel_ms.argtypes = [c_void_p]
+        lib.hxr_get_frame_timing.argtypes = [c_void_p, POINTER(FrameTiming)]
         lib.hxr_scene_destroy.argtypes = [c_void_p]
         lib.hxr_last_error.restype = c_char_p
         _hip = lib
@@ -284,13 +296,13 @@ class DeviceScene:
     """A scene resident in HBM (hxr_scene).  ``accel``: ACCEL_REFERENCE walks the kd-trees of the descriptor (the
     reference's own), ACCEL_SAH rebuilds them with the surface-area heuristic (hxr_scene_create_ex)."""
 
-    def __init__(self, host_scene: HostScene, accel: int = 0, adaptive_schedule: bool = True):
+    def __init__(self, host_scene: HostScene, accel: int = 0, adaptive_schedule: bool = True, deferred_rays: bool = False):
         if _initialised_device is None:
             init(0)
-        if accel == ACCEL_REFERENCE and adaptive_schedule:
+        if accel == ACCEL_REFERENCE and adaptive_schedule and not deferred_rays:
             self._s = hip_lib().hxr_scene_create(host_scene.desc)
         else:
-            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel, 0 if adaptive_schedule else 1, 0)
+            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel, 0 if adaptive_schedule else 1, 1 if deferred_rays else 0)
             self._s = hip_lib().hxr_scene_create_ex(host_scene.desc, ctypes.byref(opt))
         if not self._s:
             raise HipError("hxr_scene_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))
@@ -351,6 +363,12 @@ class DeviceScene:
 
     def last_kernel_ms(self) -> float:
         return hip_lib().hxr_last_kernel_ms(self._s)
+
+    def frame_timing(self) -> dict:
+        """Where the last frame's GPU time went: render / continuation / resolve kernels, deferred ray count."""
+        t = FrameTiming()
+        _check(hip_lib().hxr_get_frame_timing(self._s, ctypes.byref(t)), "hxr_get_frame_timing")
+        return t.as_dict()
 
     def close(self):
         if getattr(self, "_s", None):

@@ -15,31 +15,15 @@
 #include "hxr_kernels.hip.h"
 #include "hxr_accel.h"
 
-// compiled in hxr_kernels_heightfield.hip (-O2)
-extern template __global__ void hxr_render_kernel<false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-// compiled in hxr_kernels_mesh.hip (own scheduling flags)
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-extern template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-
+#include "hxr_variants.h"
+// compiled in hxr_kernels_mesh.hip / hxr_kernels_mesh2.hip / hxr_kernels_heightfield.hip with their own flags
+HXR_VARIANTS_MESH_DEFER(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_MESH_STACK1(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_CONTINUE)
+HXR_VARIANTS_MESH_LANEWALK(HXR_DECLARE_EXTERN_CONTINUE)
+HXR_VARIANTS_MESH_OTHER(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_HEIGHTFIELD(HXR_DECLARE_EXTERN)
 
 namespace {
 
@@ -121,7 +105,17 @@ struct hxr_scene {
 	bool sched_history = false;
 	bool aa_cost_aware = false;         // the last frame was an adaptive-AA frame whose flagged list has a back part
 	uint8_t* d_lut = nullptr;
+	// deferred secondary rays (HXR_F_DEFER variants; plan_defer)
+	bool defer_allowed = false;         // scene option hxr_scene_options::deferred_rays / HXR_DEFER=1
+	int fanout0 = 0;                    // most Reflection / Refraction rays one hit can spawn (over all nodes)
+	HxrRayRec* d_queue = nullptr;       size_t queue_bytes = 0;
+	uint32_t* d_qctl = nullptr;         // two control blocks (pass 1 / Monte-Carlo, pass 3) of QCTL_WORDS words
+	long long* d_accum = nullptr;       size_t accum_bytes = 0;
+	bool accum_dirty = false;           // a frame stopped between the continuation pass and the resolve
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t ev_pass[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per pass: before render, after render, after continuation, after resolve
+	int passes_timed = 0;
+	bool pass_deferred[2] = {false, false};
 	bool timed = false;
 	bool counters_valid = false;
 	uint64_t aa_pixels_host = 0;
@@ -134,6 +128,7 @@ namespace {
 void shader_fanout(const hxr_scene_desc* d, int si, int depth, int& rays, int& pending, bool& glossy, bool& cyclic)
 {
 	if (depth > 16) { cyclic = true; return; }
+	if (si < 0 || si >= d->num_shaders) return;   // validate() has range-checked every table reference before it walks the trees
 	const hxr_shader& s = d->shaders[si];
 	if (s.type == HXR_SHADER_REFLECTION) { rays += 1; if (s.glossiness < 1.0f) glossy = true; }
 	else if (s.type == HXR_SHADER_REFRACTION) rays += 1;
@@ -147,6 +142,29 @@ int validate(const hxr_scene_desc* d)
 {
 	if (!d || d->abi_version != HXR_ABI_VERSION) { set_err("bad descriptor / ABI version"); return HXR_E_INVALID; }
 	if (d->num_nodes < 0 || d->num_nodes > 4096) { set_err("bad node count"); return HXR_E_INVALID; }
+	if (d->num_shaders < 0 || d->num_layers < 0 || d->num_textures < 0 || d->num_bitmaps < 0 || d->num_geometries < 0 || d->num_lights < 0) {
+		set_err("negative table size");
+		return HXR_E_INVALID;
+	}
+	// every table-to-table reference is range-checked BEFORE anything follows one (the node loop below walks shader trees)
+	for (int64_t i = 0; i < d->num_textures; i++) {
+		const hxr_texture& t = d->textures[i];
+		if ((t.type == HXR_TEX_BITMAP || t.type == HXR_TEX_BUMPTEX) && (t.bitmap < 0 || t.bitmap >= d->num_bitmaps)) { set_err("bad bitmap reference"); return HXR_E_INVALID; }
+	}
+	for (int64_t i = 0; i < d->num_shaders; i++) {
+		const hxr_shader& s = d->shaders[i];
+		if (s.texture >= d->num_textures) { set_err("bad texture reference"); return HXR_E_INVALID; }
+		if (s.type == HXR_SHADER_LAYERED) {
+			if (s.num_layers < 0 || s.first_layer < 0 || (int64_t)s.first_layer + s.num_layers > d->num_layers) {
+				set_err("Layered shader %lld: layers %d..%d outside the layer table", (long long)i, s.first_layer, s.first_layer + s.num_layers);
+				return HXR_E_INVALID;
+			}
+			for (int k = 0; k < s.num_layers; k++) {
+				const hxr_layer& L = d->layers[s.first_layer + k];
+				if (L.shader < 0 || L.shader >= d->num_shaders || L.texture >= d->num_textures) { set_err("bad layer reference"); return HXR_E_INVALID; }
+			}
+		}
+	}
 	for (int64_t i = 0; i < d->num_nodes; i++) {
 		const hxr_node& n = d->nodes[i];
 		if (n.geometry < 0 || n.geometry >= d->num_geometries || n.shader < 0 || n.shader >= d->num_shaders || n.bump >= d->num_textures) {
@@ -177,19 +195,6 @@ int validate(const hxr_scene_desc* d)
 			set_err("node %lld can leave %ld secondary rays pending (limit %d)", (long long)i, need, HXR_RAY_STACK);
 			return HXR_E_UNSUPPORTED;
 		}
-	}
-	for (int64_t i = 0; i < d->num_shaders; i++) {
-		const hxr_shader& s = d->shaders[i];
-		if (s.texture >= d->num_textures) { set_err("bad texture reference"); return HXR_E_INVALID; }
-		if (s.type == HXR_SHADER_LAYERED)
-			for (int k = 0; k < s.num_layers; k++) {
-				const hxr_layer& L = d->layers[s.first_layer + k];
-				if (L.shader < 0 || L.shader >= d->num_shaders || L.texture >= d->num_textures) { set_err("bad layer reference"); return HXR_E_INVALID; }
-			}
-	}
-	for (int64_t i = 0; i < d->num_textures; i++) {
-		const hxr_texture& t = d->textures[i];
-		if ((t.type == HXR_TEX_BITMAP || t.type == HXR_TEX_BUMPTEX) && (t.bitmap < 0 || t.bitmap >= d->num_bitmaps)) { set_err("bad bitmap reference"); return HXR_E_INVALID; }
 	}
 	return 0;
 }
@@ -351,20 +356,92 @@ int grid_for(uint32_t chunks)
 	return (int)std::max(1u, std::min(blocks, need));
 }
 
-int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, bool timed)
+// `timed`: TIME_BEGIN records the start event before the launch, TIME_END the stop event after it -- hxr_last_kernel_ms() spans every
+// kernel of the frame (all three passes of an adaptive-AA frame), not just the first
+enum { TIME_BEGIN = 1, TIME_END = 2 };
+enum { QCTL_WORDS = (2 * HXR_QUEUE_SHARDS + 1) * HXR_SHARD_STRIDE };
+static_assert(HXR_SHARDS == HXR_QUEUE_SHARDS, "one sub-queue per dispenser range");
+
+// Smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h); occupancy
+// target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel).
+enum Variant { V_MESH, V_MESH_REFRACT, V_HEIGHTFIELD, V_SPHERE_GI, V_MESH_GI, V_ALL_GI_3, V_ALL_GI_2, V_ALL_3, V_ALL_2 };
+Variant pick_variant(const hxr_scene* s)
 {
-	if (timed) HIP_TRY(hipEventRecord(s->ev0, st));
+	unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
+	if (s->camera.stereo_separation != 0.0) geom |= HXR_F_EXTRA;   // the anaglyph pair lives in the catch-all variants
+	const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
+	const bool rect = (s->features & HXR_F_RECT) != 0;   // the specialised Whitted variants know PointLights only
+	const bool refr = (s->features & HXR_F_REFRACT) != 0;
+	if (!gi && !rect && !refr && (geom | HXR_F_MESH) == HXR_F_MESH) return V_MESH;
+	if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) return V_MESH_REFRACT;
+	if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) return V_HEIGHTFIELD;
+	if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) return V_SPHERE_GI;
+	if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) return V_MESH_GI;
+	if (gi) return meshes ? V_ALL_GI_3 : V_ALL_GI_2;
+	return meshes ? V_ALL_3 : V_ALL_2;
+}
+
+// Deferred secondary rays: does this launch use them, and with what queue?  Only the Whitted mesh variants have a deferring
+// build; the queue is sized for the worst case (every lane of every packet of a dispenser range emits `fanout0` rays), so an
+// append can never fail, and a frame whose worst case does not fit HXR_QUEUE_MAX_RECORDS is traced in place as before.
+#define HXR_QUEUE_MAX_RECORDS (64ull << 20)   // 5 GB of 80-byte records
+uint64_t defer_capacity(const hxr_scene* s, uint32_t num_chunks, int spp)   // records per sub-queue, 0 = this launch traces in place
+{
+	const Variant v = pick_variant(s);
+	if (!s->defer_allowed || (v != V_MESH && v != V_MESH_REFRACT) || s->fanout0 <= 0 || s->settings.max_trace_depth > 254 || spp > 65535 || num_chunks == 0) return 0;
+	const uint64_t per_shard = ((uint64_t)num_chunks + HXR_SHARDS * HXR_BATCH - 1) / (HXR_SHARDS * HXR_BATCH) * HXR_BATCH;   // as in the kernel
+	const uint64_t rounds = ((uint64_t)spp + 63) / 64;
+	const uint64_t capacity = per_shard * 64 * rounds * (uint64_t)s->fanout0;
+	if (capacity * HXR_QUEUE_SHARDS > HXR_QUEUE_MAX_RECORDS || capacity > 0xffffffffull) return 0;
+	return capacity;
+}
+
+int plan_defer(hxr_scene* s, const Plan& p, HxrLaunch& L, int pass, hipStream_t st, bool& defer)
+{
+	defer = false;
+	L.q_records = nullptr; L.q_ctl = nullptr; L.q_capacity = 0; L.q_accum = nullptr;
+	const uint64_t capacity = defer_capacity(s, L.num_chunks, L.spp);
+	if (!capacity) return 0;
+	int rc = ensure((void**)&s->d_queue, &s->queue_bytes, (size_t)capacity * HXR_QUEUE_SHARDS * sizeof(HxrRayRec));
+	if (rc) return rc;
+	const size_t need = (size_t)p.W * p.H * 3 * sizeof(long long);
+	if (s->accum_bytes < need || !s->d_accum) {
+		rc = ensure((void**)&s->d_accum, &s->accum_bytes, need);
+		if (rc) return rc;
+		s->accum_dirty = true;
+	}
+	if (s->accum_dirty) {
+		HIP_TRY(hipMemsetAsync(s->d_accum, 0, s->accum_bytes, st));
+		s->accum_dirty = false;
+	}
+	if (!s->d_qctl) HIP_TRY(hipMalloc((void**)&s->d_qctl, 2 * QCTL_WORDS * sizeof(uint32_t)));
+	L.q_ctl = s->d_qctl + (size_t)pass * QCTL_WORDS;
+	HIP_TRY(hipMemsetAsync(L.q_ctl, 0, QCTL_WORDS * sizeof(uint32_t), st));
+	L.q_records = s->d_queue;
+	L.q_capacity = (uint32_t)capacity;
+	L.q_accum = s->d_accum;
+	defer = true;
+	return 0;
+}
+
+// One pass over the frame: the render kernel and -- when its secondary rays are deferred -- the continuation and resolve kernels.
+// `pass`: 0 = pass 1 / the Monte-Carlo pass, 1 = the AA taps; `scale`: what the render kernel multiplies a pixel's sample sum by.
+int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipStream_t st, int timed, int pass, float scale)
+{
+	bool defer = false;
+	int rc = plan_defer(s, p, L, pass, st, defer);
+	if (rc) return rc;
+	if (timed & TIME_BEGIN) { HIP_TRY(hipEventRecord(s->ev0, st)); s->passes_timed = 0; }
+	s->pass_deferred[pass] = defer;
+	HIP_TRY(hipEventRecord(s->ev_pass[pass][0], st));
+	const HxrSceneDev& V = s->host_view;
+#define HXR_KERNEL_ARGS s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L
 	if (L.num_chunks > 0) {
 		int grid = grid_for(L.num_chunks);
-		const HxrSceneDev& V = s->host_view;
-#define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                     \
-	do {                                                                                                                                                     \
-		if (L.mode == 1)                                                                                                                                     \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes,         \
-			                   V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L);          \
-		else                                                                                                                                                 \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, -1>), dim3(grid), dim3(HXR_BLOCK), 0, st, s->dev, V.nodes, V.meshes,        \
-			                   V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L);          \
+#define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                      \
+	do {                                                                                                                                                      \
+		if (L.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);     \
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, -1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);                \
 	} while (0)
 #define HXR_LAUNCH_F(FEAT, WAVES)                                                         \
 	do {                                                                                  \
@@ -375,28 +452,72 @@ int launch_render(hxr_scene* s, HxrLaunch& L, bool counters, hipStream_t st, boo
 	do {                                                                                          \
 		if (counters) HXR_LAUNCH(true, COUNTED_FEAT, WAVES); else HXR_LAUNCH(false, FEAT, WAVES); \
 	} while (0)
-		// smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h);
-		// occupancy target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel)
-		unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
-		if (s->camera.stereo_separation != 0.0) geom |= HXR_F_EXTRA;   // the anaglyph pair lives in the catch-all variants
-		const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
-		const bool rect = (s->features & HXR_F_RECT) != 0;   // the specialised Whitted variants know PointLights only
-		const bool refr = (s->features & HXR_F_REFRACT) != 0;
-		if (!gi && !rect && !refr && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F2(HXR_F_MESH, HXR_F_MESH | HXR_F_REFRACT, 3);
-		else if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, 3);
-		else if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) HXR_LAUNCH_F(HXR_F_HEIGHTFIELD | HXR_F_REFRACT, 2);
-		else if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 2);
-		else if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 3);
-		else if (gi && meshes) HXR_LAUNCH_F(HXR_F_ALL, 3);
-		else if (gi) HXR_LAUNCH_F(HXR_F_ALL, 2);
-		else if (meshes) HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3);
-		else HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 2);
+		// HXR_STACK1=1: the one-slot LDS ray stack for scenes where no hit leaves more than one secondary ray waiting.  It takes the
+		// 12-entry per-lane stack out of scratch memory (private segment 1232 -> 352 B per lane) and is 2 % SLOWER on the headline frame
+		// (9.13 vs 8.91 ms; 9.02 ms with the slot in registers): the stack entries are touched once per reflected ray, what costs is the
+		// extra live state around the traversal.  Off by default; kept for the measurement.
+		const bool one_pending = s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr;
+		switch (pick_variant(s)) {
+			case V_MESH:
+				if (defer) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_DEFER, HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
+				else if (one_pending) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_STACK1, HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
+				else HXR_LAUNCH_F2(HXR_F_MESH, HXR_F_MESH | HXR_F_REFRACT, 3);
+				break;
+			case V_MESH_REFRACT:
+				if (defer) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
+				else if (one_pending) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
+				else HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, 3);
+				break;
+			case V_HEIGHTFIELD: HXR_LAUNCH_F(HXR_F_HEIGHTFIELD | HXR_F_REFRACT, 2); break;
+			case V_SPHERE_GI: HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 2); break;
+			case V_MESH_GI: HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 3); break;
+			case V_ALL_GI_3: HXR_LAUNCH_F(HXR_F_ALL, 3); break;
+			case V_ALL_GI_2: HXR_LAUNCH_F(HXR_F_ALL, 2); break;
+			case V_ALL_3: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3); break;
+			case V_ALL_2: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 2); break;
+		}
 #undef HXR_LAUNCH_F2
 #undef HXR_LAUNCH_F
 #undef HXR_LAUNCH
 		HIP_TRY(hipGetLastError());
 	}
-	if (timed) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
+	HIP_TRY(hipEventRecord(s->ev_pass[pass][1], st));
+	if (defer) {
+		// the number of queued rays stays on the device: a fixed grid of persistent waves drains the sub-queues
+		s->accum_dirty = true;
+		const bool refract = pick_variant(s) == V_MESH_REFRACT;
+		int deepest = 0;
+		for (const auto& t : s->tree_stats) deepest = std::max(deepest, t.depth);
+		L.lane_stack_entries = deepest + 2;
+		L.cont_ticket = getenv("HXR_CONT_TICKET") ? atoi(getenv("HXR_CONT_TICKET")) : 0;   // developer aid
+		const size_t lane_lds = (size_t)(HXR_LANE_BLOCK / 64) * (size_t)L.lane_stack_entries * 64 * sizeof(uint32_t);
+		// per-lane walk unless its stacks would not fit the 64 KB a block may take (trees deeper than 126 levels), or HXR_CONTINUE_PACKET=1 (A/B aid)
+		const bool lanewalk = lane_lds <= 64 * 1024 - 4096 && !getenv("HXR_CONTINUE_PACKET");
+		if (lanewalk) {
+			const int cgrid = std::max(1, g_num_cu * 16);
+			if (counters) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES>), dim3(cgrid), dim3(HXR_LANE_BLOCK), lane_lds, st, HXR_KERNEL_ARGS);
+			else if (refract) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES>), dim3(cgrid), dim3(HXR_LANE_BLOCK), lane_lds, st, HXR_KERNEL_ARGS);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH | HXR_F_LANEWALK), HXR_LANEWALK_WAVES>), dim3(cgrid), dim3(HXR_LANE_BLOCK), lane_lds, st, HXR_KERNEL_ARGS);
+		} else {
+			const int cgrid = std::max(1, g_num_cu * 4);
+			if (counters) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3>), dim3(cgrid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);
+			else if (refract) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3>), dim3(cgrid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH), 3>), dim3(cgrid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);
+		}
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(s->ev_pass[pass][2], st));
+		const uint32_t pixels = (uint32_t)p.ntiles * (uint32_t)(p.tile * p.tile) + (uint32_t)L.num_extra_pixels;
+		const int rgrid = (int)std::max(1u, std::min<uint32_t>((pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)g_num_cu * 8u));
+		hipLaunchKernelGGL(hxr_resolve_kernel, dim3(rgrid), dim3(HXR_BLOCK), 0, st, L, scale);
+		HIP_TRY(hipGetLastError());
+		s->accum_dirty = false;   // enqueued: the accumulator is zero again when this stream gets there
+	} else {
+		HIP_TRY(hipEventRecord(s->ev_pass[pass][2], st));
+	}
+	HIP_TRY(hipEventRecord(s->ev_pass[pass][3], st));
+	s->passes_timed = pass + 1;
+#undef HXR_KERNEL_ARGS
+	if (timed & TIME_END) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
 	return 0;
 }
 
@@ -514,11 +635,12 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		L.out_stride = stride;
 		L.out_tiles = p.layout == HXR_LAYOUT_TILES;
 		L.work_counter = s->d_work;
-		if (s->adaptive && L.num_chunks >= 4096) {   // small frames have no tail worth scheduling
+		// (a deferring render kernel has packets of equal length: nothing to schedule)
+		if (s->adaptive && L.num_chunks >= 4096 && !defer_capacity(s, L.num_chunks, L.spp)) {   // small frames have no tail worth scheduling
 			rc = prepare_schedule(s, p, L, tile_pixels, st);
 			if (rc) return rc;
 		}
-		return launch_render(s, L, counters, st, true);
+		return launch_render(s, p, L, counters, st, TIME_BEGIN | TIME_END, 0, L.mode == 1 ? 1.0f / (float)L.spp : 1.0f);
 	}
 
 	// adaptive AA: pass 1 -> detect -> pass 3 (src/main.cpp:253-345)
@@ -560,7 +682,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	// pass 1 records what its 64-pixel chunks cost (same machinery as the adaptive schedule, nothing listed): pass 3 of THIS
 	// frame starts with the flagged pixels of the expensive chunks, one pixel per packet
 	const uint32_t list_capacity = tile_pixels + 64u;
-	const bool cost_aware = s->adaptive && L.num_chunks >= 1024 && !getenv("HXR_AA_NO_COST");
+	const bool cost_aware = s->adaptive && L.num_chunks >= 1024 && !getenv("HXR_AA_NO_COST") && !defer_capacity(s, L.num_chunks, L.spp);
 	s->aa_cost_aware = cost_aware;
 	if (cost_aware) {
 		rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)L.num_chunks * sizeof(uint32_t));
@@ -576,7 +698,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		L.sched_ticket = (uint32_t*)s->d_sched_ctl + 8;
 		s->sched_history = false;                                // the Monte-Carlo cost map, if any, is gone
 	}
-	rc = launch_render(s, L, counters, st, true);
+	rc = launch_render(s, p, L, counters, st, TIME_BEGIN, 0, 1.0f);
 	if (rc) return rc;
 	if (tile_pixels) {
 		if (cost_aware) {
@@ -612,18 +734,16 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	}
 	L3.num_chunks = (tile_pixels + (uint32_t)L3.pixels_per_chunk - 1u) / (uint32_t)L3.pixels_per_chunk;
 	L3.work_counter = s->d_work + 256;
-	rc = launch_render(s, L3, counters, st, false);
+	rc = launch_render(s, p, L3, counters, st, TIME_END, 1, 1.0f / 5);
 	if (rc) return rc;
-	if (!direct) {
-		if (p.layout == HXR_LAYOUT_TILES) {
-			if (tile_pixels) {
-				int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, 2048u);
-				hipLaunchKernelGGL(hxr_extract_tiles_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, d_out);
-				HIP_TRY(hipGetLastError());
-			}
-		} else {
-			HIP_TRY(hipMemcpy2DAsync(d_out, stride, frame, fstride, (size_t)p.W * 12, p.H, hipMemcpyDeviceToDevice, st));
-		}
+	if (!direct && tile_pixels) {
+		// Only this shard's own pixels leave the scratch frame (tile-major, or in place for FRAME layout): the rest of it holds
+		// halo colours of pass 1 and whatever an earlier frame left there.  Pixels of other shards in the caller's frame stay
+		// untouched, exactly like sharded SINGLE / MONTE_CARLO frames.
+		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, 2048u);
+		hipLaunchKernelGGL(hxr_extract_tiles_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, d_out, stride,
+		                   p.layout == HXR_LAYOUT_TILES ? 1 : 0);
+		HIP_TRY(hipGetLastError());
 	}
 	return 0;
 }
@@ -667,6 +787,13 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	const bool adaptive = !(opt && opt->no_adaptive_schedule) && !getenv("HXR_NO_ADAPTIVE_SCHEDULE");
 	hxr_scene* s = new hxr_scene;
 	s->adaptive = adaptive;
+	s->defer_allowed = ((opt && opt->deferred_rays) || getenv("HXR_DEFER")) && !getenv("HXR_NO_DEFER");
+	for (int64_t i = 0; i < d->num_nodes; i++) {   // validate() has bounded this walk
+		int rays = 0, pending = 1;
+		bool glossy = false, cyclic = false;
+		shader_fanout(d, d->nodes[i].shader, 0, rays, pending, glossy, cyclic);
+		s->fanout0 = std::max(s->fanout0, rays);
+	}
 	auto fail = [&]() -> hxr_scene* { hxr_scene_destroy(s); return nullptr; };
 	HxrSceneDev& V = s->host_view;
 	memset(&V, 0, sizeof V);
@@ -882,6 +1009,9 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (s->arena.upload(lut, 4097, &dl)) return fail();
 	s->d_lut = const_cast<uint8_t*>(dl);
 	if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
+	for (int pass = 0; pass < 2; pass++)
+		for (int k = 0; k < 4; k++)
+			if (hipEventCreate(&s->ev_pass[pass][k]) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
 	return s;
 }
 
@@ -945,6 +1075,12 @@ int hxr_render(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_
 	rc = render_on_stream(s, fp, s->d_frame, dstride, nullptr);
 	if (rc) return rc;
 	HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, s->d_frame, dstride, dstride, p.H, hipMemcpyDeviceToHost));
+	for (int pass = 0; pass < s->passes_timed; pass++)
+		if (s->pass_deferred[pass]) {   // cannot happen (the queue is sized for the worst case); a frame with dropped rays must not pass silently
+			uint32_t overflow = 0;
+			HIP_TRY(hipMemcpy(&overflow, s->d_qctl + (size_t)pass * QCTL_WORDS + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE, sizeof overflow, hipMemcpyDeviceToHost));
+			if (overflow) { set_err("the deferred-ray queue overflowed"); return HXR_E_HIP; }
+		}
 	if (cancel && *cancel) return HXR_CANCELLED;
 	if (cb)
 		for (int i = 0; i < p.ntiles; i++) {
@@ -1053,6 +1189,45 @@ double hxr_last_kernel_ms(const hxr_scene* s)
 	return ms;
 }
 
+int hxr_get_frame_timing(const hxr_scene* s, hxr_frame_timing* out)
+{
+	if (!s || !out) { set_err("null argument"); return HXR_E_INVALID; }
+	memset(out, 0, sizeof *out);
+	if (!s->timed || s->passes_timed <= 0) { set_err("no frame has been rendered"); return HXR_E_INVALID; }
+	HIP_TRY(hipEventSynchronize(s->ev1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+	out->total_ms = ms;
+	for (int pass = 0; pass < s->passes_timed; pass++) {
+		float a = 0, b = 0, c = 0;
+		HIP_TRY(hipEventElapsedTime(&a, s->ev_pass[pass][0], s->ev_pass[pass][1]));
+		HIP_TRY(hipEventElapsedTime(&b, s->ev_pass[pass][1], s->ev_pass[pass][2]));
+		HIP_TRY(hipEventElapsedTime(&c, s->ev_pass[pass][2], s->ev_pass[pass][3]));
+		out->render_ms += a;
+		out->continue_ms += b;
+		out->resolve_ms += c;
+		if (s->pass_deferred[pass] && s->d_qctl) {
+			uint32_t ctl[QCTL_WORDS];
+			HIP_TRY(hipMemcpy(ctl, s->d_qctl + (size_t)pass * QCTL_WORDS, sizeof ctl, hipMemcpyDeviceToHost));
+			for (int q = 0; q < HXR_QUEUE_SHARDS; q++) out->deferred_rays += ctl[q * HXR_SHARD_STRIDE];
+#ifdef HXR_CONT_CLOCKS
+			{
+				const uint32_t* dbg = ctl + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE;
+				fprintf(stderr, "continuation tickets: %u, mean %.0f kclk, longest %u kclk; longer than 131k/262k/524k/1M/2M/4M/8M/16M clocks: %u %u %u %u %u %u %u %u\n", dbg[2],
+				        dbg[2] ? (double)dbg[3] / dbg[2] : 0.0, dbg[1], dbg[4], dbg[5], dbg[6], dbg[7], dbg[8], dbg[9], dbg[10], dbg[11]);
+			}
+#endif
+			if (ctl[2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE]) { set_err("the ray queue overflowed (internal error: it is sized for the worst case)"); return HXR_E_HIP; }
+		}
+	}
+	if (s->passes_timed > 1) {   // the detect kernel between the passes of an adaptive-AA frame
+		float gap = 0;
+		HIP_TRY(hipEventElapsedTime(&gap, s->ev_pass[0][3], s->ev_pass[1][0]));
+		out->resolve_ms += gap;
+	}
+	return 0;
+}
+
 void hxr_scene_destroy(hxr_scene* s)
 {
 	if (!s) return;
@@ -1068,8 +1243,14 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_sched_ctl) (void)hipFree(s->d_sched_ctl);
 	if (s->d_sched_side) (void)hipFree(s->d_sched_side);
 	if (s->d_sched_part) (void)hipFree(s->d_sched_part);
+	if (s->d_queue) (void)hipFree(s->d_queue);
+	if (s->d_qctl) (void)hipFree(s->d_qctl);
+	if (s->d_accum) (void)hipFree(s->d_accum);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
+	for (int pass = 0; pass < 2; pass++)
+		for (int k = 0; k < 4; k++)
+			if (s->ev_pass[pass][k]) (void)hipEventDestroy(s->ev_pass[pass][k]);
 	delete s;
 }
 

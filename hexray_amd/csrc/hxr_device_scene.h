@@ -106,6 +106,19 @@ struct HxrSceneDev {
 	const int32_t* hot_ids;     // triangle number (local to its mesh) of each hot record
 };
 
+// A secondary ray that the render kernel hands to the continuation pass instead of tracing it in place (HXR_F_DEFER variants):
+// everything raytrace() needs to go on -- the ray, the product of blend / reflectance factors on the way to it, and the identity
+// of the sample for the random numbers.  80 bytes, written by one lane with five 16-byte stores.
+struct alignas(16) HxrRayRec {
+	double o[3], d[3];
+	float weight[3];
+	uint32_t key;            // ray key of the counter-based generator (hxr_rng.hip.h)
+	uint32_t pixel;          // y * W + x
+	uint32_t sample_depth;   // bits 0..15 sample number, 16..23 Ray::depth, 24..31 Ray::flags
+	uint32_t pad_[2];
+};
+#define HXR_QUEUE_SHARDS 8   // sub-queues = dispenser ranges (HXR_SHARDS in hxr_kernels.hip.h): one append counter each
+
 // One frame's launch parameters (kernel argument, wave-uniform).
 struct HxrLaunch {
 	int32_t W, H;              // frame size
@@ -141,4 +154,14 @@ struct HxrLaunch {
 	uint32_t* sched_part_done;       // [part slot] parts finished
 	const uint32_t* sched_part_pixels;   // [part slot] pixel number
 	int32_t sched_part_groups;       // parts per pixel (0: level disabled)
+	// Deferred secondary rays (HXR_F_DEFER variants; hxr_api.hip, plan_defer).  The render kernel appends the Reflection / Refraction
+	// rays of its hits to q_records instead of tracing them; hxr_continue_kernel traces them to the end, 64 unrelated rays per wave,
+	// and adds what they contribute to their pixels into q_accum as 64-bit fixed point (integer addition commutes: the frame does
+	// not depend on the order in which waves finish); hxr_resolve_kernel folds q_accum into the frame and clears it.
+	HxrRayRec* q_records;            // HXR_QUEUE_SHARDS sub-queues of q_capacity records each
+	uint32_t* q_ctl;                 // [shard * 32] records appended, [(8 + shard) * 32] records handed out, [16 * 32] overflow flag
+	uint32_t q_capacity;             // records per sub-queue: the packets of its dispenser range cannot emit more (0: nothing is deferred)
+	long long* q_accum;              // [W * H][3] colour sums in units of 2^-32
+	int32_t lane_stack_entries;      // per-lane-walk continuation kernels: rows of the per-lane stack (deepest tree + 2)
+	int32_t cont_ticket;             // continuation kernels: rays per ticket (0 = 64, a full wave)
 };

@@ -40,7 +40,19 @@ enum : unsigned {
 	HXR_F_EXTRA = 32u,                                                              // CSG geometry, glossy Reflection, anaglyph camera
 	HXR_F_RECT = 64u,                                                               // RectLight (every light is a PointLight otherwise)
 	HXR_F_REFRACT = 128u,                                                           // glass and water: Refraction shader in the Whitted work list, Fresnel and Bumps textures
-	HXR_F_ALL = 255u
+	HXR_F_ALL = 255u,
+	// Whitted only: a hit's Reflection / Refraction rays are appended to a global queue (one ballot + prefix count + atomic per
+	// group of lanes) instead of waiting on a per-lane stack; hxr_continue_kernel traces them, re-packed 64 to a wave.  The
+	// render kernel then holds camera rays and their shadow rays only -- packets of equal length, no per-lane ray stack.
+	HXR_F_DEFER = 256u,
+	// Mesh::intersect walked by every lane for itself (vector loads, a per-lane stack in LDS) instead of by the wave as a packet:
+	// for rays that have nothing in common -- the continuation pass re-packs secondary rays of unrelated pixels into one wave --
+	// a packet walk visits the union of 64 paths one after the other, a per-lane walk visits them side by side.
+	HXR_F_LANEWALK = 512u,
+	// Whitted, in place: no hit of the scene spawns more than ONE secondary ray (a Layered shader with one Reflection or Refraction
+	// layer, ...), so at most one ray is ever pending per lane.  It waits in LDS (18 dwords per lane, a row per dword) instead of on
+	// the 12-entry per-lane stack, which is a dynamically indexed array and therefore lives in scratch memory.
+	HXR_F_STACK1 = 1024u
 };
 
 // counters (COUNT builds only); order = hxr_counters
@@ -413,6 +425,59 @@ struct WaveStack {
 	int32_t node[HXR_KD_STACK];
 	uint32_t mask_lo[HXR_KD_STACK], mask_hi[HXR_KD_STACK];
 };
+// Per-lane traversal stack of the per-lane walk (mesh_query_lane): a column of 32-bit node numbers per lane in LDS
+struct LaneStack {
+	uint32_t* rows;     // this wave's `entries` rows x 64 lanes
+	int entries;        // the deepest tree of the scene + 2
+	uint32_t* overflow; // raised if a push would not fit (cannot happen: sized from the trees at launch)
+};
+// what a traversal may use: the packet walk's per-wave stack, or the per-lane walk's columns (HXR_F_LANEWALK variants)
+struct Stacks {
+	WaveStack* wave;
+	LaneStack lane;
+	uint32_t* pend;     // HXR_F_STACK1 variants: this wave's pending-ray slot, HXR_PEND_DWORDS rows x 64 lanes
+};
+#define HXR_PEND_DWORDS 18   // RayItem: o, d (6 dwords each), weight (3), depth, flags, key
+
+// Mesh::intersectTriangle (src/mesh.cpp:178-195) against the running best hit `g`, and the leaf rule of Mesh::intersectKD
+// (src/mesh.cpp:228): returns true when the triangle is accepted AND its hit point lies in the leaf's box.  One definition for the
+// packet walk (record and index wave-uniform: scalar loads) and the per-lane walk (vector loads).
+HXR_DEV bool triangle_test(const HxrMeshDev& M, const HxrTriHot& T, int id, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g)
+{
+	bool ok = true;
+	if (M.backface_culling) {
+		const hxr_triangle& ct = M.tris[id];
+		ok = !(dot(d, ld3(ct.gnormal)) > 0);
+	}
+	// The four sign / magnitude rejections are evaluated without branching between them: the lanes of a
+	// packet fail at different ones, so nested early-outs only add mask bookkeeping (8 levels of it).
+	d3 N = ld3(T.N);
+	double Dcr = dot(N, nd);
+	d3 H = o - ld3(T.A);
+	bool neg = Dcr < 0;
+	double ga = dot(N, H);
+	double gb = dot(cross(H, ld3(T.AC)), nd);
+	double gc = dot(cross(ld3(T.AB), H), nd);
+	ok = ok & !(fabs(Dcr) < 1e-12)
+	        & !(((ga < 0) != neg) & (ga != 0))    // gamma < 0
+	        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
+	        & !(((gc < 0) != neg) & (gc != 0));   // lambda3 < 0
+	bool inside = false;
+	if (ok) {
+		double rD = 1 / Dcr;
+		double gamma = ga * rD, l2 = gb * rD, l3 = gc * rD;
+		double l1 = 1 - (l2 + l3);
+		bool take = !(gamma < 0 || gamma > g.t) & !(l2 < 0 || l2 > 1) & !(l3 < 0 || l3 > 1) & !(l1 < 0 || l1 > 1);
+		if (take) {
+			g.t = gamma;
+			g.l2 = l2;
+			g.l3 = l3;
+			g.tri = id;
+			inside = box_holds(box, o + d * gamma);
+		}
+	}
+	return inside;
+}
 
 // Leaf of Mesh::intersectKD (src/mesh.cpp:223-232): every triangle is tested against the running
 // best distance; a hit counts for THIS leaf only if its point lies in the leaf's box.
@@ -424,7 +489,7 @@ struct WaveStack {
 // and stay in SGPRs, so a triangle costs the lanes no vector registers.
 template <bool COUNT>
 HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, bool mine, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g,
-                        WaveStack& st, Tally<COUNT>& tl)
+                        const Stacks& st, Tally<COUNT>& tl)
 {
 	bool found = false;
 	tl.template lap<PH_MESH>();
@@ -448,37 +513,7 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 		for (int i = 0; i < count; i++) {
 			tl.add(HC_TRI);
 			tl.add(HC_LEAFIDX);
-			bool ok = true;
-			if (M.backface_culling) {
-				const hxr_triangle& ct = M.tris[ids[i]];
-				ok = !(dot(d, ld3(ct.gnormal)) > 0);
-			}
-			// The four sign / magnitude rejections are evaluated without branching between them: the lanes of a
-			// packet fail at different ones, so nested early-outs only add mask bookkeeping (8 levels of it).
-			d3 N = ld3(T[i].N);
-			double Dcr = dot(N, nd);
-			d3 H = o - ld3(T[i].A);
-			bool neg = Dcr < 0;
-			double ga = dot(N, H);
-			double gb = dot(cross(H, ld3(T[i].AC)), nd);
-			double gc = dot(cross(ld3(T[i].AB), H), nd);
-			ok = ok & !(fabs(Dcr) < 1e-12)
-			        & !(((ga < 0) != neg) & (ga != 0))    // gamma < 0
-			        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
-			        & !(((gc < 0) != neg) & (gc != 0));   // lambda3 < 0
-			if (ok) {
-				double rD = 1 / Dcr;
-				double gamma = ga * rD, l2 = gb * rD, l3 = gc * rD;
-				double l1 = 1 - (l2 + l3);
-				bool take = !(gamma < 0 || gamma > g.t) & !(l2 < 0 || l2 > 1) & !(l3 < 0 || l3 > 1) & !(l1 < 0 || l1 > 1);
-				if (take) {
-					g.t = gamma;
-					g.l2 = l2;
-					g.l3 = l3;
-					g.tri = ids[i];
-					if (box_holds(box, o + d * gamma)) found = true;
-				}
-			}
+			if (triangle_test(M, T[i], ids[i], box, o, d, nd, g)) found = true;
 		}
 	}
 	tl.template lap<PH_LEAF>();
@@ -505,7 +540,7 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 // counters are per lane and equal the reference's per-ray counts (a box test is counted for a lane only when
 // that lane's own traversal makes it).
 template <bool COUNT>
-HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
+HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, const Stacks& st, Tally<COUNT>& tl)
 {
 	const unsigned long long me = 1ull << (threadIdx.x & 63);
 	tl.template lap<PH_QUERY>();
@@ -551,10 +586,10 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			const bool go_left = lm != 0;
 			const unsigned long long next_mask = go_left ? lm : rm;
 			if (lm && rm) {
-				st.node[sp] = left; st.mask_lo[sp] = (uint32_t)rm; st.mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
-				st.node[sp] = left + 1; st.mask_lo[sp] = (uint32_t)mask; st.mask_hi[sp] = (uint32_t)(mask >> 32); sp++;
+				st.wave->node[sp] = left; st.wave->mask_lo[sp] = (uint32_t)rm; st.wave->mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
+				st.wave->node[sp] = left + 1; st.wave->mask_lo[sp] = (uint32_t)mask; st.wave->mask_hi[sp] = (uint32_t)(mask >> 32); sp++;
 			} else {
-				st.node[sp] = go_left ? left + 1 : left; st.mask_lo[sp] = (uint32_t)next_mask; st.mask_hi[sp] = (uint32_t)(next_mask >> 32); sp++;
+				st.wave->node[sp] = go_left ? left + 1 : left; st.wave->mask_lo[sp] = (uint32_t)next_mask; st.wave->mask_hi[sp] = (uint32_t)(next_mask >> 32); sp++;
 			}
 			// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
 			const int moved = go_left ? axis : axis + 3;   // which of the six bounds becomes the split position
@@ -582,8 +617,8 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		// otherwise the next pending visit whose lanes are still searching and whose box at least one of them reaches
 		while (!descended && sp > 0) {
 			sp--;
-			int cn = __builtin_amdgcn_readfirstlane(st.node[sp]);
-			unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.mask_lo[sp]);
+			int cn = __builtin_amdgcn_readfirstlane(st.wave->node[sp]);
+			unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.wave->mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.wave->mask_lo[sp]);
 			unsigned long long m = pm & alive;
 			if (!m) continue;
 			HxrKdSlim C = kd[cn];
@@ -606,6 +641,88 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	}
 	tl.template lap<PH_MESH>();
 	return found;
+}
+
+// Mesh::intersect (src/mesh.cpp:247-263) walked by each lane for its own ray: the reference's recursion
+// (src/mesh.cpp:221-245) with an explicit stack.  At a binary node the child on the origin's side is tried first; the other
+// child waits on the stack UNTESTED and its box is only tested when the first subtree has come back empty-handed, like the
+// reference's `if (childBB[i].testIntersect(ray) && intersectKD(...)) return true`, so the work counters are the per-ray
+// counts of the reference and of the packet walk.  Node and triangle records arrive through per-lane vector loads; the stack
+// is a column of 32-bit node numbers per lane in LDS (`entries` rows: the deepest tree of the scene + 2).
+template <bool COUNT>
+HXR_DEV bool mesh_query_lane(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, const LaneStack& ls, Tally<COUNT>& tl)
+{
+	const int lane = threadIdx.x & 63;
+	const HxrKdSlim* kd = S.kd + M.kd_first;
+	const HxrKdBox* kd_box = S.kd_box + M.kd_first;
+	Box cb{ld3(M.bbox_min), ld3(M.bbox_max)};
+	const d3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z), nd = -d;
+	g.t = HXR_INF;
+	g.tri = -1;
+	if (!box_test<COUNT>(cb, o, d, inv, tl)) return false;
+	const HxrTriHot* hot = S.hot + M.hot_first;
+	const int32_t* ids = S.hot_ids + M.hot_first;
+	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
+		const Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
+		for (int i = 0; i < M.num_triangles; i++) {
+			tl.add(HC_TRI);
+			tl.add(HC_LEAFIDX);
+			triangle_test(M, hot[i], ids[i], everything, o, d, nd, g);
+		}
+		return g.t < HXR_INF;
+	}
+	tl.add(HC_KD);
+	int node = 0, sp = 0;
+	for (;;) {
+		const HxrKdSlim R = kd[node];
+		const int ac = R.axis_count, axis = ac & 3;
+		bool descended = false;
+		if (axis == HXR_KD_LEAF) {
+			bool found = false;
+			const int first = R.first, count = ac >> 2;
+			for (int i = 0; i < count; i++) {
+				tl.add(HC_TRI);
+				tl.add(HC_LEAFIDX);
+				if (triangle_test(M, hot[first + i], ids[first + i], cb, o, d, nd, g)) found = true;
+			}
+			if (found) return true;
+		} else {
+			const double split = R.split;
+			const bool right_first = comp(o, axis) > split;
+			const int near = R.first + (right_first ? 1 : 0), far = R.first + (right_first ? 0 : 1);
+			if (sp < ls.entries) ls.rows[sp * 64 + lane] = (uint32_t)far;
+			else *ls.overflow = 1u;
+			sp++;
+			// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
+			const int moved = right_first ? axis + 3 : axis;
+			Box nb;
+			nb.hi.x = moved == 0 ? split : cb.hi.x;
+			nb.hi.y = moved == 1 ? split : cb.hi.y;
+			nb.hi.z = moved == 2 ? split : cb.hi.z;
+			nb.lo.x = moved == 3 ? split : cb.lo.x;
+			nb.lo.y = moved == 4 ? split : cb.lo.y;
+			nb.lo.z = moved == 5 ? split : cb.lo.z;
+			if (box_test<COUNT>(nb, o, d, inv, tl)) {
+				tl.add(HC_KD);
+				node = near;
+				cb = nb;
+				descended = true;
+			}
+		}
+		while (!descended && sp > 0) {   // the next pending child whose box the ray reaches
+			sp--;
+			const int cn = sp < ls.entries ? (int)ls.rows[sp * 64 + lane] : 0;
+			const HxrKdBox CB = kd_box[cn];
+			const Box pb{ld3(CB.lo), ld3(CB.hi)};
+			if (box_test<COUNT>(pb, o, d, inv, tl)) {
+				tl.add(HC_KD);
+				node = cn;
+				cb = pb;
+				descended = true;
+			}
+		}
+		if (!descended) return false;
+	}
 }
 
 // intersectTriangleFast, src/mesh.cpp:131-170
@@ -696,7 +813,7 @@ HXR_DEV d3 heightfield_normal(const HxrHeightfieldDev& F, float x, float y)
 // nodes
 // ------------------------------------------------------------------------------------------------
 template <bool COUNT, unsigned F>
-HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, GeomHit& g, WaveStack& st, Tally<COUNT>& tl)
+HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 dl, GeomHit& g, const Stacks& st, Tally<COUNT>& tl)
 {
 	switch (N.geom_type) {
 		case HXR_GEOM_PLANE: return plane_query(N.p, ol, dl, g);
@@ -707,7 +824,10 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 			if constexpr ((F & HXR_F_CUBE) != 0) return cube_query(N.p, ol, dl, g);
 			return false;
 		case HXR_GEOM_MESH:
-			if constexpr ((F & HXR_F_MESH) != 0) return mesh_query<COUNT>(S, S.meshes[N.ref], ol, dl, g, st, tl);
+			if constexpr ((F & HXR_F_MESH) != 0) {
+				if constexpr ((F & HXR_F_LANEWALK) != 0) return mesh_query_lane<COUNT>(S, S.meshes[N.ref], ol, dl, g, st.lane, tl);
+				else return mesh_query<COUNT>(S, S.meshes[N.ref], ol, dl, g, st, tl);
+			}
 			return false;
 		case HXR_GEOM_HEIGHTFIELD:
 			if constexpr ((F & HXR_F_HEIGHTFIELD) != 0) return heightfield_query<COUNT>(S.heightfields[N.ref], ol, dl, g, tl);
@@ -740,7 +860,7 @@ HXR_DEV d3 local_hit_point(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 
 
 // Node::intersect (src/geometry.cpp:196-208) up to the world-space distance
 template <bool COUNT, unsigned F>
-HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, WaveStack& st, Tally<COUNT>& tl)
+HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, const Stacks& st, Tally<COUNT>& tl)
 {
 	const HxrNodeDev& N = S.nodes[__builtin_amdgcn_readfirstlane(ni)];   // the node scan is wave-uniform: scalar loads
 	tl.add(HC_NODE);
@@ -1028,7 +1148,7 @@ HXR_DEVX f3 environment_lookup(const HxrSceneDev& S, d3 dir, Tally<COUNT>& tl)
 // hit closer than |AB|).  Both compare `info.dist < limit`; raycast lowers the limit as it goes,
 // visible() leaves the scan at the first success.  Returns the node index or -1.
 template <bool COUNT, unsigned F>
-HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any, GeomHit& bg, double& bw, WaveStack& st, Tally<COUNT>& tl)
+HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any, GeomHit& bg, double& bw, const Stacks& st, Tally<COUNT>& tl)
 {
 	int node = -1;
 	bw = limit;
@@ -1055,6 +1175,37 @@ struct RayItem {
 	int depth;
 	uint32_t flags, key;
 };
+
+// Where a deferring kernel variant appends secondary rays (wave-uniform; see HxrLaunch::q_*)
+struct DeferCtx {
+	HxrRayRec* records;    // this packet's sub-queue
+	uint32_t* count;       // its append counter
+	uint32_t* overflow;    // raised if a record would not fit (cannot happen: the host sizes the queue for the worst case)
+	uint32_t capacity;
+};
+
+// Append this lane's ray.  Called from divergent code: the lanes that reach it together (same shader, same work-list step) are
+// numbered with ballot + prefix count, the first of them reserves the slots with ONE atomic, each stores its own 80-byte record.
+HXR_DEV void emit_ray(const DeferCtx& q, d3 o, d3 d, f3 weight, int depth, uint32_t flags, uint32_t key, uint32_t pixel, uint32_t sample)
+{
+	const unsigned long long group = hxr_ballot(true);
+	const int lane = threadIdx.x & 63;
+	const uint32_t rank = (uint32_t)__popcll(group & ((1ull << lane) - 1ull));
+	uint32_t base = 0;
+	if (rank == 0) base = atomicAdd(q.count, (uint32_t)__popcll(group));
+	base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // rank 0 is the first active lane
+	const uint32_t slot = base + rank;
+	if (slot >= q.capacity) { *q.overflow = 1u; return; }
+	HxrRayRec rec;
+	rec.o[0] = o.x; rec.o[1] = o.y; rec.o[2] = o.z;
+	rec.d[0] = d.x; rec.d[1] = d.y; rec.d[2] = d.z;
+	rec.weight[0] = weight.x; rec.weight[1] = weight.y; rec.weight[2] = weight.z;
+	rec.key = key;
+	rec.pixel = pixel;
+	rec.sample_depth = (sample & 0xffffu) | ((uint32_t)(depth & 0xff) << 16) | ((flags & 0xffu) << 24);
+	rec.pad_[0] = rec.pad_[1] = 0u;
+	q.records[slot] = rec;
+}
 
 // A pending entry of the per-lane ray stack.  With glossy Reflection compiled in, an entry can also be a
 // GENERATOR: `left` more samples of shader `shader` are still to be shot from r.o (surface point), with r.d the
@@ -1120,19 +1271,61 @@ enum { Q_NONE = 0, Q_CLOSEST = 1, Q_SHADOW = 2 };
 		for (const int uni = gather_records ? (var) : __builtin_amdgcn_readfirstlane(var); !wf_done_ && (var) == uni; wf_done_ = true)
 
 template <bool COUNT, unsigned F>
-HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
+HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& rc, const Stacks& st, Tally<COUNT>& tl, const DeferCtx& dq)
 {
 	constexpr bool gi = (F & HXR_F_GI) != 0;   // the launcher picks the variant that matches settings.gi
 	constexpr bool glossy = (F & HXR_F_EXTRA) != 0;
 	constexpr bool gather_records = gi;
 	constexpr bool rect = (F & HXR_F_RECT) != 0;   // RectLight code only where the scene has one
-	StackItem<glossy> stack[HXR_RAY_STACK];
+	constexpr bool defer = (F & HXR_F_DEFER) != 0; // secondary rays go to the queue: `top` stays 0, the stack is never touched
+	constexpr bool one = (F & HXR_F_STACK1) != 0;  // at most one pending ray: it waits in LDS (st.pend)
+	static_assert(!defer || (!gi && !glossy), "deferral is for the Whitted variants without glossy generators");
+	static_assert(!one || (!gi && !glossy && !defer), "the one-slot stack is for the in-place Whitted variants");
+	StackItem<glossy> stack[(defer || one) ? 1 : HXR_RAY_STACK];
+	const int pend_lane = threadIdx.x & 63;
+	auto pend_store = [&](const RayItem& r) {   // HXR_F_STACK1: the pending ray, one LDS row per dword (conflict-free)
+#ifdef HXR_PEND_IN_REGS
+		stack[0].r = r;
+		return;
+#endif
+		uint32_t* p = st.pend + pend_lane;
+		const double v[6] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z};
+#pragma unroll
+		for (int k = 0; k < 6; k++) {
+			const unsigned long long b = __builtin_bit_cast(unsigned long long, v[k]);
+			p[(2 * k) * 64] = (uint32_t)b;
+			p[(2 * k + 1) * 64] = (uint32_t)(b >> 32);
+		}
+		p[12 * 64] = __builtin_bit_cast(uint32_t, r.weight.x);
+		p[13 * 64] = __builtin_bit_cast(uint32_t, r.weight.y);
+		p[14 * 64] = __builtin_bit_cast(uint32_t, r.weight.z);
+		p[15 * 64] = (uint32_t)r.depth;
+		p[16 * 64] = r.flags;
+		p[17 * 64] = r.key;
+	};
+	auto pend_load = [&]() {
+#ifdef HXR_PEND_IN_REGS
+		return stack[0].r;
+#endif
+		const uint32_t* p = st.pend + pend_lane;
+		double v[6];
+#pragma unroll
+		for (int k = 0; k < 6; k++) v[k] = __builtin_bit_cast(double, ((unsigned long long)p[(2 * k + 1) * 64] << 32) | p[(2 * k) * 64]);
+		return RayItem{mk3(v[0], v[1], v[2]), mk3(v[3], v[4], v[5]),
+		               mkf(__builtin_bit_cast(float, p[12 * 64]), __builtin_bit_cast(float, p[13 * 64]), __builtin_bit_cast(float, p[14 * 64])),
+		               (int)p[15 * 64], p[16 * 64], p[17 * 64]};
+	};
 	int sh_stack[HXR_SHADER_STACK];
 	f3 w_stack[HXR_SHADER_STACK];
 	int top = 0, stop = 0;
 	f3 acc = mkf(0, 0, 0);
-	RayItem cur{o0, d0, mkf(1, 1, 1), 0, 0u, 0u};
+	RayItem cur = start;
 	auto pop_ray = [&]() {   // top > 0: the next pending ray becomes `cur`
+		if constexpr (one) {
+			cur = pend_load();
+			top = 0;
+			return;
+		}
 		StackItem<glossy>& e = stack[top - 1];
 		if constexpr (glossy) {
 			if (e.left > 0) {
@@ -1425,7 +1618,14 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 							case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
 							case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy: generator entry below)
 								d3 n = faceforward(cur.d, hp.norm);
-								if (top < HXR_RAY_STACK) {
+								if constexpr (defer) {
+									emit_ray(dq, hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0), rc.pixel, rc.sample);
+								} else if constexpr (one) {
+									if (top == 0) {
+										pend_store(RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)});
+										top = 1;
+									}
+								} else if (top < HXR_RAY_STACK) {
 									StackItem<glossy>& e = stack[top++];
 									e.r = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
 									if constexpr (glossy) {
@@ -1446,7 +1646,14 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, d3 o0, d3 d0, const RngCtx& rc, Wave
 								if constexpr ((F & HXR_F_REFRACT) != 0) {
 									d3 out;
 									bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
-									if (ok && top < HXR_RAY_STACK) {
+									if constexpr (defer) {
+										if (ok) emit_ray(dq, hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0), rc.pixel, rc.sample);
+									} else if constexpr (one) {
+										if (ok && top == 0) {
+											pend_store(RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)});
+											top = 1;
+										}
+									} else if (ok && top < HXR_RAY_STACK) {
 										StackItem<glossy>& e = stack[top++];
 										e.r = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
 										if constexpr (glossy) e.left = 0;
@@ -1497,7 +1704,7 @@ HXR_DEV void camera_ray(const HxrSceneDev& S, int W, int H, double x, double y, 
 }
 
 template <bool COUNT, unsigned F>
-HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, const RngCtx& rc, WaveStack& st, Tally<COUNT>& tl)
+HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, const RngCtx& rc, const Stacks& st, Tally<COUNT>& tl, const DeferCtx& dq)
 {
 	double lu = 0, lv = 0;
 	tl.add(HC_SAMPLES);
@@ -1516,14 +1723,14 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	if ((F & HXR_F_EXTRA) == 0 || S.camera.stereo_separation == 0.0) {
 		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
 		tl.template lap<PH_GEN>();
-		f3 c = trace_rays<COUNT, F>(S, o, d, rc, st, tl);
+		f3 c = trace_rays<COUNT, F>(S, RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u}, rc, st, tl, dq);
 		tl.template lap<PH_SHADE>();
 		return c;
 	}
 	f3 eye[2];
 	for (int e = 0; e < 2; e++) {   // anaglyph pair (src/main.cpp:237-247)
 		camera_ray(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
-		eye[e] = trace_rays<COUNT, F>(S, o, d, rc, st, tl);
+		eye[e] = trace_rays<COUNT, F>(S, RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u}, rc, st, tl, dq);
 	}
 	float ml = intensity(eye[0]), mr = intensity(eye[1]);
 	return mkf(ml + (eye[0].x - ml) * 0.3f, mr + (eye[1].y - mr) * 0.3f, mr + (eye[1].z - mr) * 0.3f);
@@ -1624,6 +1831,8 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	S.geometries = a_geoms;
 	__shared__ WaveStack lds_stack[HXR_BLOCK / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__shared__ uint32_t lds_pend[(F & HXR_F_STACK1) != 0 ? (HXR_BLOCK / 64) * HXR_PEND_DWORDS * 64 : 1];
+	const Stacks stacks{&lds_stack[wave], LaneStack{nullptr, 0, nullptr}, lds_pend + ((F & HXR_F_STACK1) != 0 ? wave * HXR_PEND_DWORDS * 64 : 0)};
 	Tally<COUNT> tl;
 	tl.clear();
 #ifdef HXR_PHASE_TIMERS
@@ -1713,6 +1922,11 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			}
 		}
 		tl.template lap<PH_MAP>();
+		DeferCtx dq{nullptr, nullptr, nullptr, 0u};
+		if constexpr ((F & HXR_F_DEFER) != 0) {   // the sub-queue of this packet's dispenser range
+			const uint32_t qs = min(chunk / max(per_shard, 1u), (uint32_t)(HXR_QUEUE_SHARDS - 1));
+			dq = DeferCtx{P.q_records + (size_t)qs * P.q_capacity, P.q_ctl + qs * HXR_SHARD_STRIDE, P.q_ctl + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE, P.q_capacity};
+		}
 		f3 sum = mkf(0, 0, 0);
 		if (live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group)) {
 			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
@@ -1732,7 +1946,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 					sx = (double)((float)x + kx[s]);
 					sy = (double)((float)y + ky[s]);
 				}
-				f3 c = trace_sample<COUNT, F>(S, P.W, P.H, sx, sy, rc, lds_stack[wave], tl);
+				f3 c = trace_sample<COUNT, F>(S, P.W, P.H, sx, sy, rc, stacks, tl, dq);
 				sum = (rd == 0) ? c : sum + c;
 			}
 		}
@@ -1822,6 +2036,115 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// the continuation kernel: secondary rays deferred by the render kernel, 64 to a wave
+// ------------------------------------------------------------------------------------------------
+// A deferring render kernel (HXR_F_DEFER) leaves the Reflection / Refraction rays of its hits in HXR_QUEUE_SHARDS sub-queues.
+// Here persistent waves take 64 consecutive records at a time -- rays of neighbouring pixels, whatever packet they came from,
+// so a wave is full where the render kernel would have gone on with the few lanes of a packet that hit something shiny --
+// and every lane runs raytrace() on its ray to the end (further bounces wait on the per-lane stack as before).  What the ray
+// contributes to its pixel is `weight x colour` by linearity; it is added into HxrLaunch::q_accum as 64-bit fixed point, so the
+// sum does not depend on the order in which waves finish.  F: the in-place variant of the integrator (no HXR_F_DEFER).
+#define HXR_ACCUM_SCALE 4294967296.0f   // 2^32: one unit = 2.3e-10, range +-2.1e9
+#define HXR_LANE_BLOCK 128   // threads per block of the per-lane-walk continuation kernels: two waves share 2 x entries x 256 B of LDS
+template <bool COUNT, unsigned F, int W>
+__global__ __launch_bounds__(((F & HXR_F_LANEWALK) != 0 ? HXR_LANE_BLOCK : HXR_BLOCK), W) void hxr_continue_kernel(
+    const HxrSceneDev* __restrict__ Sp, const HxrNodeDev* __restrict__ a_nodes, const HxrMeshDev* __restrict__ a_meshes,
+    const HxrHeightfieldDev* __restrict__ a_hfs, const HxrBitmapDev* __restrict__ a_bitmaps, const hxr_texture* __restrict__ a_textures,
+    const hxr_shader* __restrict__ a_shaders, const hxr_layer* __restrict__ a_layers, const hxr_light* __restrict__ a_lights,
+    const HxrKdSlim* __restrict__ a_kd, const HxrKdBox* __restrict__ a_kd_box, const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids,
+    const hxr_geometry* __restrict__ a_geoms, HxrLaunch P)
+{
+	static_assert((F & HXR_F_DEFER) == 0, "the continuation pass traces in place");
+	constexpr bool lanewalk = (F & HXR_F_LANEWALK) != 0;
+	constexpr int block = lanewalk ? HXR_LANE_BLOCK : HXR_BLOCK;
+	HxrSceneDev S = *Sp;
+	S.nodes = a_nodes;
+	S.meshes = a_meshes;
+	S.heightfields = a_hfs;
+	S.bitmaps = a_bitmaps;
+	S.textures = a_textures;
+	S.shaders = a_shaders;
+	S.layers = a_layers;
+	S.lights = a_lights;
+	S.kd = a_kd;
+	S.kd_box = a_kd_box;
+	S.hot = a_hot;
+	S.hot_ids = a_hot_ids;
+	S.geometries = a_geoms;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__shared__ WaveStack lds_stack[lanewalk ? 1 : block / 64];   // the packet walk's stacks (unused by the per-lane walk)
+	extern __shared__ uint32_t lds_lane_rows[];                   // the per-lane walk's columns: P.lane_stack_entries rows x 64 lanes per wave
+	const Stacks stacks{&lds_stack[lanewalk ? 0 : wave],
+	                    LaneStack{lds_lane_rows + (size_t)wave * (size_t)P.lane_stack_entries * 64, P.lane_stack_entries, P.q_ctl + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE},
+	                    nullptr};
+	Tally<COUNT> tl;
+	tl.clear();
+#ifdef HXR_PHASE_TIMERS
+	__shared__ unsigned long long lds_clock[block / 64][PH_NUM + 1];
+	tl.attach(lds_clock[wave]);
+#endif
+	uint32_t shard = blockIdx.x & (HXR_QUEUE_SHARDS - 1), shards_done = 0;
+	const DeferCtx none{nullptr, nullptr, nullptr, 0u};
+	while (shards_done < HXR_QUEUE_SHARDS) {   // every wave leaves after at most HXR_QUEUE_SHARDS empty-handed tickets
+		const uint32_t appended = min(P.q_ctl[shard * HXR_SHARD_STRIDE], P.q_capacity);
+		uint32_t t = 0;
+		const uint32_t ticket = P.cont_ticket > 0 ? (uint32_t)P.cont_ticket : 64u;   // rays per ticket (developer aid: fewer than a wave)
+		if (lane == 0) t = atomicAdd(P.q_ctl + (HXR_QUEUE_SHARDS + shard) * HXR_SHARD_STRIDE, ticket);
+		t = __builtin_amdgcn_readfirstlane(t);
+		if (t >= appended) {
+			shard = (shard + 1) & (HXR_QUEUE_SHARDS - 1);
+			shards_done++;
+			continue;
+		}
+		tl.template lap<PH_DISPENSE>();
+#ifdef HXR_CONT_CLOCKS
+		const unsigned long long ticket_t0 = __builtin_readcyclecounter();
+#endif
+		if ((uint32_t)lane < ticket && t + (uint32_t)lane < appended) {
+			const HxrRayRec rec = P.q_records[(size_t)shard * P.q_capacity + t + (uint32_t)lane];
+			const RngCtx rc{P.seed, rec.pixel, rec.sample_depth & 0xffffu};
+			const RayItem ray{mk3(rec.o[0], rec.o[1], rec.o[2]), mk3(rec.d[0], rec.d[1], rec.d[2]), mkf(rec.weight[0], rec.weight[1], rec.weight[2]),
+			                  (int)((rec.sample_depth >> 16) & 0xffu), rec.sample_depth >> 24, rec.key};
+			tl.template lap<PH_GEN>();
+			const f3 c = trace_rays<COUNT, F>(S, ray, rc, stacks, tl, none);
+			tl.template lap<PH_SHADE>();
+			unsigned long long* acc = (unsigned long long*)P.q_accum + (size_t)rec.pixel * 3;
+			if (c.x != 0) atomicAdd(acc + 0, (unsigned long long)(long long)(c.x * HXR_ACCUM_SCALE));
+			if (c.y != 0) atomicAdd(acc + 1, (unsigned long long)(long long)(c.y * HXR_ACCUM_SCALE));
+			if (c.z != 0) atomicAdd(acc + 2, (unsigned long long)(long long)(c.z * HXR_ACCUM_SCALE));
+		}
+#ifdef HXR_CONT_CLOCKS   // developer aid: how long do the tickets (64 rays) of the continuation pass take?  words after the overflow flag:
+		{                    // [1] longest, [2] count, [3] sum (all in units of 1024 clocks), [4 + k] tickets longer than 2^(17 + k) clocks
+			const unsigned long long dt = __builtin_readcyclecounter() - ticket_t0;
+			uint32_t* dbg = P.q_ctl + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE;
+			if (lane == 0) {
+				atomicMax(dbg + 1, (uint32_t)(dt >> 10));
+				atomicAdd(dbg + 2, 1u);
+				atomicAdd(dbg + 3, (uint32_t)(dt >> 10));
+				for (int k = 0; k < 10; k++)
+					if (dt > (1ull << (17 + k))) atomicAdd(dbg + 4 + k, 1u);
+			}
+		}
+#endif
+		tl.template lap<PH_REDUCE>();
+	}
+#ifdef HXR_PHASE_TIMERS
+	if (P.counters && lane == 0) {
+#ifndef HXR_PACKET_CLOCKS
+		for (int i = 0; i < PH_NUM; i++) atomicAdd(&P.counters[HC_NUM + i], (unsigned long long)tl.ph[i]);
+#endif
+	}
+#endif
+	if (COUNT && P.counters) {
+		for (int i = 0; i < HC_NUM; i++) {
+			uint32_t v = tl.c[i];
+			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+			if (lane == 0 && v) atomicAdd(&P.counters[i], (unsigned long long)v);
+		}
+	}
+}
+
 #ifndef HXR_RENDER_KERNEL_ONLY   // the small kernels below live in hxr_api.hip only
 // Adaptive schedule, step 1: total cost of the previous frame's chunks.
 __global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t n, unsigned long long* total)
@@ -1873,6 +2196,35 @@ __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc,
 	}
 }
 
+// Deferred secondary rays, last step: what the continuation pass added up for a pixel (HxrLaunch::q_accum, 2^-32 units) goes into
+// the frame -- `scale` = 1 / spp for Monte-Carlo frames, 1 for pass 1, 1 / 5 for the AA taps, like the sums the render kernel wrote --
+// and the accumulator is left cleared for the next pass.  Own tile pixels of the shard, then the halo pixels of a sharded AA pass 1.
+__global__ __launch_bounds__(HXR_BLOCK) void hxr_resolve_kernel(HxrLaunch P, float scale)
+{
+	const uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+	const uint32_t total = tile_pixels + (uint32_t)P.num_extra_pixels;
+	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+		int x, y;
+		float* dst;
+		if (q < tile_pixels) {
+			if (!shard_pixel(P, q, x, y)) continue;
+			dst = out_pixel(P, q, x, y);
+		} else {
+			const int pix = P.extra_pixels[q - tile_pixels];
+			x = pix % P.W;
+			y = pix / P.W;
+			dst = (float*)((char*)P.out + (size_t)y * P.out_stride) + (size_t)x * 3;
+		}
+		long long* acc = P.q_accum + ((size_t)y * P.W + x) * 3;
+		const long long r = acc[0], g = acc[1], b = acc[2];
+		if ((r | g | b) == 0) continue;
+		acc[0] = 0; acc[1] = 0; acc[2] = 0;
+		dst[0] += (float)((double)r * (1.0 / 4294967296.0)) * scale;
+		dst[1] += (float)((double)g * (1.0 / 4294967296.0)) * scale;
+		dst[2] += (float)((double)b * (1.0 / 4294967296.0)) * scale;
+	}
+}
+
 // Autofocus probe of renderWithMonteCarlo (src/main.cpp:350-362): the distance to the closest node along the
 // ray through the frame centre becomes the focal plane distance.  One wavefront, every lane the same ray.
 __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
@@ -1880,7 +2232,8 @@ __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
     const HxrHeightfieldDev* __restrict__ a_hfs, const hxr_geometry* __restrict__ a_geoms, const HxrKdSlim* __restrict__ a_kd, const HxrKdBox* __restrict__ a_kd_box,
     const HxrTriHot* __restrict__ a_hot, const int32_t* __restrict__ a_hot_ids, int W, int H, double* focal_out)
 {
-	__shared__ WaveStack st;
+	__shared__ WaveStack wave_stack;
+	const Stacks st{&wave_stack, LaneStack{nullptr, 0, nullptr}, nullptr};
 	HxrSceneDev S = *Sp;
 	S.nodes = a_nodes;
 	S.meshes = a_meshes;
@@ -1944,8 +2297,9 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, c
 	}
 }
 
-// own tiles of a row-major frame -> tile-major shard buffer (sharded adaptive-AA frames render into a scratch frame)
-__global__ void hxr_extract_tiles_kernel(HxrLaunch P, const float* __restrict__ frame, size_t stride, float* tiles)
+// own tiles of a row-major scratch frame -> the caller's buffer: tile-major (`as_tiles`) or row-major with `dst_stride` bytes per row
+// (sharded adaptive-AA frames render into a scratch frame; only the shard's own pixels are handed over)
+__global__ void hxr_extract_tiles_kernel(HxrLaunch P, const float* __restrict__ frame, size_t stride, float* dst_base, size_t dst_stride, int as_tiles)
 {
 	uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
 	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < tile_pixels; q += gridDim.x * blockDim.x) {
@@ -1953,8 +2307,9 @@ __global__ void hxr_extract_tiles_kernel(HxrLaunch P, const float* __restrict__ 
 		if (!shard_pixel(P, q, x, y)) continue;
 		const float* src = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
 		HxrLaunch T = P;
-		T.out = tiles;
-		T.out_tiles = 1;
+		T.out = dst_base;
+		T.out_stride = dst_stride;
+		T.out_tiles = as_tiles;
 		float* dst = out_pixel(T, q, x, y);
 		dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 	}

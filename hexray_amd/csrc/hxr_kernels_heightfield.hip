@@ -5,8 +5,6 @@
 #include "hexray_hip.h"
 #define HXR_RENDER_KERNEL_ONLY
 #include "hxr_kernels.hip.h"
+#include "hxr_variants.h"
 
-template __global__ void hxr_render_kernel<false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+HXR_VARIANTS_HEIGHTFIELD(HXR_INSTANTIATE)

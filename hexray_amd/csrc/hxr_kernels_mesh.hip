@@ -1,27 +1,15 @@
-// The variants of the render kernel that walk kd-trees (3 waves per SIMD), in a translation unit of their own so that they can
-// be compiled at -O2 (2 % faster than -O3 here: 9.03 -> 8.85 ms) with `-mllvm -amdgpu-sched-strategy=max-ilp`: the packet kd walk gains from that scheduling strategy (headline
-// frame 9.85 -> 9.60 ms, cornell box 66.5 -> 65.5 ms), the heightfield marcher loses 3 % and the sphere path tracer is
-// indifferent, so those stay with the default in hxr_api.hip (which declares the ones below `extern template`).
+// The Whitted variants of the render kernel that walk kd-trees (3 waves per SIMD) and their continuation kernels, in a translation
+// unit of their own so that they can be compiled at -O2 (2 % faster than -O3 here: 9.03 -> 8.85 ms) with
+// `-mllvm -amdgpu-sched-strategy=max-ilp`: the packet kd walk gains from that scheduling strategy (headline frame 9.85 -> 9.60 ms),
+// the heightfield marcher loses 3 % and the sphere path tracer is indifferent (see hxr_variants.h, build.sh).
 #include <hip/hip_runtime.h>
 #include "hexray_hip.h"
 #define HXR_RENDER_KERNEL_ONLY
 #include "hxr_kernels.hip.h"
+#include "hxr_variants.h"
 
-template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_MESH), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_ALL), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_ALL), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<false, (HXR_F_ALL & ~HXR_F_GI), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3, 1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
-template __global__ void hxr_render_kernel<true, (HXR_F_ALL & ~HXR_F_GI), 3, -1>(const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*, const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch);
+HXR_VARIANTS_MESH_DEFER(HXR_INSTANTIATE)
+HXR_VARIANTS_MESH_INPLACE(HXR_INSTANTIATE)
+HXR_VARIANTS_MESH_STACK1(HXR_INSTANTIATE)
+HXR_VARIANTS_MESH_INPLACE(HXR_INSTANTIATE_CONTINUE)
+HXR_VARIANTS_MESH_LANEWALK(HXR_INSTANTIATE_CONTINUE)

@@ -1,0 +1,9 @@
+// Path tracing over meshes and the catch-all variants for scenes with meshes: same flags as hxr_kernels_mesh.hip (cornell box
+// 66.5 -> 65.5 ms under max-ilp), a unit of their own so that the two compile side by side.
+#include <hip/hip_runtime.h>
+#include "hexray_hip.h"
+#define HXR_RENDER_KERNEL_ONLY
+#include "hxr_kernels.hip.h"
+#include "hxr_variants.h"
+
+HXR_VARIANTS_MESH_OTHER(HXR_INSTANTIATE)

@@ -1,0 +1,58 @@
+// The compiled variants of the render kernel (hxr_kernels.hip.h: template <COUNT, F, W, M>), listed ONCE.
+// Each X(COUNT, F, W) stands for the two render modes known at compile time (M = 1 Monte-Carlo, M = -1 taken from
+// HxrLaunch::mode).  Translation units instantiate their list (HXR_INSTANTIATE), hxr_api.hip declares the lists of the
+// other units `extern template` (HXR_DECLARE_EXTERN) and instantiates the rest implicitly at its launch sites.
+// Which unit a variant lives in decides its compiler flags (build.sh): the kd-walking variants gain from -O2 and the
+// max-ilp scheduling strategy, the heightfield marcher from -O2 with the default strategy, the sphere path tracer from -O3.
+#pragma once
+
+#define HXR_KERNEL_PARAMS                                                                                                                              \
+	const HxrSceneDev*, const HxrNodeDev*, const HxrMeshDev*, const HxrHeightfieldDev*, const HxrBitmapDev*, const hxr_texture*, const hxr_shader*,     \
+	    const hxr_layer*, const hxr_light*, const HxrKdSlim*, const HxrKdBox*, const HxrTriHot*, const int32_t*, const hxr_geometry*, HxrLaunch
+
+// hxr_kernels_mesh.hip: Whitted over meshes, deferring secondary rays to the continuation pass (the default for mesh scenes)
+#define HXR_VARIANTS_MESH_DEFER(X)                         \
+	X(false, (HXR_F_MESH | HXR_F_DEFER), 3)                \
+	X(false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER), 3) \
+	X(true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER), 3)
+// ... and the same integrator tracing secondary rays in place: the continuation pass runs these (hxr_continue_kernel), and so
+// do frames whose ray queue would not fit (hxr_api.hip, plan_defer)
+#define HXR_VARIANTS_MESH_INPLACE(X)          \
+	X(false, (HXR_F_MESH), 3)                 \
+	X(false, (HXR_F_MESH | HXR_F_REFRACT), 3) \
+	X(true, (HXR_F_MESH | HXR_F_REFRACT), 3)
+// ... with at most one secondary ray pending per lane (no Layered shader of the scene has two Reflection / Refraction layers): the
+// default for mesh scenes -- the per-lane ray stack leaves scratch memory
+#define HXR_VARIANTS_MESH_STACK1(X)                              \
+	X(false, (HXR_F_MESH | HXR_F_STACK1), 3)                     \
+	X(false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1), 3)     \
+	X(true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1), 3)
+// ... and the continuation kernels that walk the trees lane by lane (hxr_kernels_mesh.hip as well)
+#ifndef HXR_LANEWALK_WAVES
+#define HXR_LANEWALK_WAVES 4   // waves per SIMD the per-lane-walk kernels are compiled for
+#endif
+#define HXR_VARIANTS_MESH_LANEWALK(X)                                               \
+	X(false, (HXR_F_MESH | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)                     \
+	X(false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)     \
+	X(true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)
+// hxr_kernels_mesh2.hip: path tracing over meshes and the catch-alls for scenes with meshes
+#define HXR_VARIANTS_MESH_OTHER(X)                                      \
+	X(false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3)   \
+	X(true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3)    \
+	X(false, (HXR_F_ALL), 3)                                            \
+	X(true, (HXR_F_ALL), 3)                                             \
+	X(false, (HXR_F_ALL & ~HXR_F_GI), 3)                                \
+	X(true, (HXR_F_ALL & ~HXR_F_GI), 3)
+// hxr_kernels_heightfield.hip
+#define HXR_VARIANTS_HEIGHTFIELD(X)                  \
+	X(false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2) \
+	X(true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2)
+
+#define HXR_INSTANTIATE(C, F, W)                                                    \
+	template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
+	template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
+#define HXR_DECLARE_EXTERN(C, F, W)                                                        \
+	extern template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
+	extern template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
+#define HXR_INSTANTIATE_CONTINUE(C, F, W) template __global__ void hxr_continue_kernel<C, F, W>(HXR_KERNEL_PARAMS);
+#define HXR_DECLARE_EXTERN_CONTINUE(C, F, W) extern template __global__ void hxr_continue_kernel<C, F, W>(HXR_KERNEL_PARAMS);

@@ -323,7 +323,11 @@ typedef struct hxr_scene_options {
 	                             expensive in the previous frame of the same size / mode / shard are started first and split
 	                             into one-pixel packets -- a schedule only, every frame still traces every sample and the
 	                             image does not depend on it ("adaptive schedule") */
-	int32_t reserved_;
+	int32_t deferred_rays;    /* 1: Whitted frames over meshes append the Reflection / Refraction rays of their hits to a queue and a
+	                             continuation pass traces them re-packed, 64 unrelated rays per wavefront, each lane walking the
+	                             kd-trees for itself.  Default (0): they are traced in place, on a per-lane
+	                             stack, inside the render kernel.  Same rays, same work counters; the frames of the two settings
+	                             differ at float rounding level (summation order). */
 } hxr_scene_options;
 
 /* hxr_scene_create with options (NULL = defaults = hxr_scene_create). */
@@ -379,6 +383,18 @@ int hxr_get_counters(const hxr_scene* scene, hxr_counters* out);
 /* Milliseconds the dominant render kernel took in the last hxr_render / hxr_render_device call that
  * has completed (HIP events on the launch stream); negative if unknown. */
 double hxr_last_kernel_ms(const hxr_scene* scene);
+
+/* Where the last frame's GPU time went (HIP events on the launch stream; blocks until the frame has finished).  An adaptive-AA
+ * frame is two rounds of render -> continuation -> resolve with the detect kernel between them; the fields are sums over both. */
+typedef struct hxr_frame_timing {
+	double total_ms;          /* first kernel of the frame to the last: what hxr_last_kernel_ms() returns */
+	double render_ms;         /* hxr_render_kernel: camera rays, their shading and shadow rays (+ everything, when nothing is deferred) */
+	double continue_ms;       /* hxr_continue_kernel: the deferred secondary rays; 0 when nothing is deferred */
+	double resolve_ms;        /* hxr_resolve_kernel (+ the AA detect kernel) */
+	uint64_t deferred_rays;   /* records the render kernel(s) appended to the ray queue */
+	uint64_t reserved_[3];
+} hxr_frame_timing;
+int hxr_get_frame_timing(const hxr_scene* scene, hxr_frame_timing* out);
 
 void hxr_scene_destroy(hxr_scene* scene);
 

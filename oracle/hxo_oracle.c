@@ -64,6 +64,10 @@ typedef struct {
 	uint32_t pixel, sample; /* RNG counter words of the camera sample being traced */
 	double focal_plane_dist; /* Camera::focalPlaneDist, possibly replaced by the autofocus probe */
 	hxr_counters cnt;
+	/* unit-level probing (hxo_shade_probe): raytrace() calls are recorded instead of traced, like the recording raytrace() the
+	   reference's shading.cpp is linked against in oracle/ref_harness_shading.cpp */
+	double* probe_rays; /* 8 doubles per recorded ray: start, dir, depth, flags */
+	int probe_max, probe_count, probe_on;
 } ctx_t;
 
 /* ------------------------------------------------------------------ vector / colour helpers */
@@ -314,6 +318,16 @@ static int mesh_triangle(ctx_t* cx, const hxr_mesh* m, const hxr_triangle* t, co
 }
 
 /* Mesh::intersectKD, src/mesh.cpp:221-245: recursive, carries the node's box */
+/* BBox::split, src/bbox.h:210-216 */
+static void box_split(const box_t* box, int axis, double where, box_t* left, box_t* right)
+{
+	*left = *box;
+	*right = *box;
+	if (axis == 0) { left->hi.x = where; right->lo.x = where; }
+	else if (axis == 1) { left->hi.y = where; right->lo.y = where; }
+	else { left->hi.z = where; right->lo.z = where; }
+}
+
 static int mesh_kd(ctx_t* cx, const hxr_mesh* m, int node, const box_t* box, const ray_t* ray, hit_t* h)
 {
 	const hxr_scene_desc* sc = cx->sc;
@@ -329,10 +343,8 @@ static int mesh_kd(ctx_t* cx, const hxr_mesh* m, int node, const box_t* box, con
 		}
 		return found;
 	}
-	box_t kid[2] = {*box, *box};
-	if (n->axis == 0) { kid[0].hi.x = n->split; kid[1].lo.x = n->split; }
-	else if (n->axis == 1) { kid[0].hi.y = n->split; kid[1].lo.y = n->split; }
-	else { kid[0].hi.z = n->split; kid[1].lo.z = n->split; }
+	box_t kid[2];
+	box_split(box, n->axis, n->split, &kid[0], &kid[1]);
 	int first = vget(ray->start, n->axis) > n->split ? 1 : 0;
 	for (int i = 0; i < 2; i++) {
 		int c = i == 0 ? first : 1 - first;
@@ -814,6 +826,29 @@ static int refract_dir(vec i, vec n, float ior, vec* out)
 
 static col shade(ctx_t* cx, int si, const ray_t* ray, const hit_t* h);
 
+/* one turn of unitDiskSample's loop (src/util.cpp:101-107): two uniform draws -> a point of [-1,1]^2; returns 1 when it is accepted */
+static int disk_map(double u, double v, double* x, double* y)
+{
+	*x = u * 2 - 1;
+	*y = v * 2 - 1;
+	return !(*x * *x + *y * *y > 1);
+}
+
+/* one turn of the glossy loop of Reflection::computeColor (src/shading.cpp:165-179) for an accepted disk point (x, y):
+   perturb the face-forwarded normal `n` in its othonormedBasis (src/vector.h:194-207) and reflect `dir` about it */
+static vec glossy_dir(vec n, vec dir, float glossiness, double x, double y)
+{
+	float scaling = powf(10.0f, 2 - 8 * glossiness);
+	vec t0 = V(0.577350269, 0.577350269, 0.577350269), t1 = V(0.267261242, -0.534522484, 0.801783726);
+	vec tv = fabs(vdot(n, t0)) > 0.9 ? t1 : t0;
+	vec bu = vunit(vcross(tv, n));
+	vec bv = vcross(bu, n);
+	x *= scaling;
+	y *= scaling;
+	vec mn = vunit(vadd(n, vadd(vmul(bu, x), vmul(bv, y))));
+	return vreflect(dir, mn);
+}
+
 /* Reflection::computeColor, src/shading.cpp:159-187 */
 static col shade_reflection(ctx_t* cx, int si, const hxr_shader* s, const ray_t* ray, const hit_t* h)
 {
@@ -822,29 +857,21 @@ static col shade_reflection(ctx_t* cx, int si, const hxr_shader* s, const ray_t*
 	nr.start = vadd(h->ip, vmul(n, 1e-6));
 	nr.depth = ray->depth + 1;
 	if (s->glossiness < 1.0f) {
-		float scaling = powf(10.0f, 2 - 8 * s->glossiness);
-		/* othonormedBasis, src/vector.h:194-207 */
-		vec t0 = V(0.577350269, 0.577350269, 0.577350269), t1 = V(0.267261242, -0.534522484, 0.801783726);
-		vec tv = fabs(vdot(n, t0)) > 0.9 ? t1 : t0;
-		vec bu = vunit(vcross(tv, n));
-		vec bv = vcross(bu, n);
 		col sum = C(0, 0, 0);
 		for (int i = 0; i < s->num_samples; i++) {
 			vec refl = n;
 			for (uint32_t attempt = 0;; attempt++) {
-				/* unitDiskSample inside the rejection loop: each outer attempt draws one accepted disk point */
-				double x = 0, y = 0;
+				/* unitDiskSample inside the rejection loop: each outer attempt draws one accepted disk point.  Both loops are
+				   unbounded in the reference; here they stop after 8 turns (p ~ 5e-6 per sample), and the HIP kernel does the same */
+				double x = 0, y = 0, u, v;
 				uint32_t inner = 0;
+				int accepted;
 				do {
-					hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, ray->key, 0x2000000u + (uint32_t)i * 64u + ((attempt * 8u + inner) & 63u)), &x, &y);
-					x = x * 2 - 1;
-					y = y * 2 - 1;
+					hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, ray->key, 0x2000000u + (uint32_t)i * 64u + ((attempt * 8u + inner) & 63u)), &u, &v);
+					accepted = disk_map(u, v, &x, &y);
 					inner++;
-				} while (x * x + y * y > 1 && inner < 8);
-				x *= scaling;
-				y *= scaling;
-				vec mn = vunit(vadd(n, vadd(vmul(bu, x), vmul(bv, y))));
-				refl = vreflect(ray->dir, mn);
+				} while (!accepted && inner < 8);
+				refl = glossy_dir(n, ray->dir, s->glossiness, x, y);
 				if (!(vdot(refl, n) < 0) || attempt >= 7) break;
 			}
 			nr.dir = refl;
@@ -901,6 +928,16 @@ static col shade(ctx_t* cx, int si, const ray_t* ray, const hit_t* h)
 /* raytrace(), src/main.cpp:105-113 */
 static col trace_ray(ctx_t* cx, const ray_t* ray)
 {
+	if (cx->probe_on) { /* unit-level probing: record the ray, answer with the colour the reference harness's raytrace() answers */
+		if (cx->probe_count < cx->probe_max) {
+			double* r = cx->probe_rays + 8 * cx->probe_count;
+			r[0] = ray->start.x; r[1] = ray->start.y; r[2] = ray->start.z;
+			r[3] = ray->dir.x; r[4] = ray->dir.y; r[5] = ray->dir.z;
+			r[6] = ray->depth; r[7] = ray->flags;
+		}
+		cx->probe_count++;
+		return C((float)(0.2 + 0.6 * fabs(ray->dir.x)), (float)(0.2 + 0.6 * fabs(ray->dir.y)), (float)(0.2 + 0.6 * fabs(ray->dir.z)));
+	}
 	hit_t h;
 	int node;
 	col early;
@@ -1052,10 +1089,9 @@ static col trace_sample(ctx_t* cx, double x, double y)
 	cx->cnt.camera_samples++;
 	if (sc->camera.dof) { /* unitDiskSample, src/util.cpp:101-107 */
 		for (uint32_t attempt = 0; attempt < 64; attempt++) {
-			hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, 0, 16 + attempt), &lu, &lv);
-			lu = lu * 2 - 1;
-			lv = lv * 2 - 1;
-			if (!(lu * lu + lv * lv > 1)) break;
+			double u, v;
+			hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, 0, 16 + attempt), &u, &v);
+			if (disk_map(u, v, &lu, &lv)) break;
 		}
 	}
 	int passes = sc->camera.stereo_separation == 0.0 ? 1 : 2;
@@ -1318,6 +1354,111 @@ void hxo_camera_ray(const hxr_scene_desc* sc, int W, int H, double x, double y, 
 	ray_t r = camera_ray(&cx, x, y, dof, lu, lv, 0);
 	out6[0] = r.start.x; out6[1] = r.start.y; out6[2] = r.start.z;
 	out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;
+}
+
+/* ---- shading members pinned by tests/golden/reference_shading_vectors.json (oracle/ref_harness_shading.cpp) ---- */
+typedef struct {   /* the fields of IntersectionInfo a shader / texture reads */
+	double ip[3], norm[3], dNdx[3], dNdy[3], u, v;
+} hxo_probe_hit;
+
+static hit_t probe_hit(const hxo_probe_hit* p)
+{
+	hit_t h;
+	memset(&h, 0, sizeof h);
+	h.ip = vld(p->ip); h.norm = vld(p->norm); h.dNdx = vld(p->dNdx); h.dNdy = vld(p->dNdy);
+	h.u = p->u; h.v = p->v;
+	return h;
+}
+
+void hxo_box_split(const double* lo, const double* hi, int axis, double where, double* out12)
+{
+	box_t b = {vld(lo), vld(hi)}, l, r;
+	box_split(&b, axis, where, &l, &r);
+	const vec v[4] = {l.lo, l.hi, r.lo, r.hi};
+	for (int i = 0; i < 4; i++) { out12[3 * i] = v[i].x; out12[3 * i + 1] = v[i].y; out12[3 * i + 2] = v[i].z; }
+}
+
+void hxo_hemisphere(double u, double v, const double* normal, double* out3)
+{
+	vec d = hemisphere(u, v, vld(normal));
+	out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;
+}
+
+int hxo_disk_map(double u, double v, double* xy) { return disk_map(u, v, &xy[0], &xy[1]); }
+
+void hxo_glossy_dir(const double* n, const double* dir, float glossiness, double x, double y, double* out3)
+{
+	vec d = glossy_dir(vld(n), vld(dir), glossiness, x, y);
+	out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;
+}
+
+void hxo_texture_sample(const hxr_scene_desc* sc, int texture, const double* dir, const hxo_probe_hit* hit, float* out3)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	hit_t h = probe_hit(hit);
+	col c = texture_sample(&cx, texture, vld(dir), &h);
+	out3[0] = c.r; out3[1] = c.g; out3[2] = c.b;
+}
+
+void hxo_texture_bump(const hxr_scene_desc* sc, int texture, hxo_probe_hit* hit)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	hit_t h = probe_hit(hit);
+	texture_bump(&cx, texture, &h);
+	hit->norm[0] = h.norm.x; hit->norm[1] = h.norm.y; hit->norm[2] = h.norm.z;
+}
+
+/* Shader::computeColor of shader `shader` with raytrace() replaced by a recorder: returns the number of rays it asked for,
+   the first `max_rays` of them in rays[8 * i] = start, dir, depth, flags */
+int hxo_shade_probe(const hxr_scene_desc* sc, int shader, const double* start, const double* dir, int depth, unsigned flags, const hxo_probe_hit* hit, float* out3,
+                    double* rays, int max_rays)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	cx.probe_on = 1;
+	cx.probe_rays = rays;
+	cx.probe_max = max_rays;
+	ray_t r;
+	memset(&r, 0, sizeof r);
+	r.start = vld(start); r.dir = vld(dir); r.depth = depth; r.flags = flags;
+	hit_t h = probe_hit(hit);
+	col c = shade(&cx, shader, &r, &h);
+	out3[0] = c.r; out3[1] = c.g; out3[2] = c.b;
+	return cx.probe_count;
+}
+
+void hxo_brdf_eval(const hxr_scene_desc* sc, int shader, const hxo_probe_hit* hit, const double* w_in, const double* w_out, float* out3)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	hit_t h = probe_hit(hit);
+	col c = brdf_eval(&cx, sc->shaders + shader, &h, vld(w_in), vld(w_out));
+	out3[0] = c.r; out3[1] = c.g; out3[2] = c.b;
+}
+
+/* BRDF::spawnRay; out8 = start, dir, depth, flags of w_out (which starts as a copy of the incoming ray, src/main.cpp:124-128) */
+void hxo_brdf_spawn(const hxr_scene_desc* sc, int shader, const hxo_probe_hit* hit, const double* start, const double* dir, int depth, unsigned flags, double* out8,
+                    float* color3, float* pdf)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	ray_t in, out;
+	memset(&in, 0, sizeof in);
+	in.start = vld(start); in.dir = vld(dir); in.depth = depth; in.flags = flags;
+	out = in;
+	hit_t h = probe_hit(hit);
+	col c;
+	brdf_spawn(&cx, shader, &h, &in, &out, &c, pdf);
+	out8[0] = out.start.x; out8[1] = out.start.y; out8[2] = out.start.z; out8[3] = out.dir.x; out8[4] = out.dir.y; out8[5] = out.dir.z;
+	out8[6] = out.depth; out8[7] = out.flags;
+	color3[0] = c.r; color3[1] = c.g; color3[2] = c.b;
 }
 
 void hxo_philox_words(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t key, uint32_t dim, uint32_t* out4)

@@ -21,7 +21,7 @@ def declared_functions(header):
 
 def test_hip_library_exports_every_declared_symbol():
     names = declared_functions(os.path.join(ROOT, "include", "hexray_hip.h"))
-    assert len(names) == 18
+    assert len(names) >= 19
     lib = ctypes.CDLL(hx.HIP_LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libhexray_hip.so does not export {n}"

@@ -364,3 +364,97 @@ def test_cost_aware_aa_pass_is_invisible(gpu):
     ds.assemble_frame(p0, torch.cat(parts).data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, st)
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy(), plain)
+
+
+def test_sharded_adaptive_aa_into_a_row_major_frame(gpu):
+    """shard_count > 1 with HXR_LAYOUT_FRAME in adaptive-AA mode: the shard's own pixels equal the whole frame's, and every
+    other pixel of the caller's frame is left as it was (like sharded SINGLE / MONTE_CARLO frames) -- no halo colours, no
+    stale scratch contents."""
+    import torch
+    W, H, world, tile = 200, 152, 3, 16
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(W, H))
+    ds = hx.DeviceScene(hs)
+    fp = dict(mode=hx.MODE_ADAPTIVE_AA)
+    whole = ds.render(hx.frame_params(**fp))
+    st = torch.cuda.current_stream().cuda_stream
+    SENTINEL = -7.0
+    union = np.zeros((H, W), dtype=np.int32)
+    for layout_mode in (hx.MODE_ADAPTIVE_AA, hx.MODE_SINGLE):
+        for rank in range(world):
+            p = hx.frame_params(mode=layout_mode, tile_size=tile, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_FRAME)
+            frame = torch.full((H, W, 3), SENTINEL, dtype=torch.float32, device="cuda")
+            ds.render_device(p, frame.data_ptr(), W * 12, st)
+            torch.cuda.synchronize()
+            got = frame.cpu().numpy()
+            own = np.zeros((H, W), dtype=bool)
+            for (x0, y0, x1, y1) in ds.shard_tiles(p):
+                own[y0:y1, x0:x1] = True
+            assert own.any()
+            assert np.all(got[~own] == SENTINEL)                       # pixels of other shards: untouched
+            if layout_mode == hx.MODE_ADAPTIVE_AA:
+                assert np.array_equal(got[own], whole[own])            # own pixels: the whole frame's, bit for bit
+                union += own
+    assert np.all(union == 1)                                          # the shards tile the frame exactly once
+    ds.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# hxr_scene_options.deferred_rays: secondary rays queued by the render kernel (ballot + prefix count + one atomic per group of
+# lanes), traced by the continuation kernel with a per-lane kd walk, folded into the frame from 64-bit fixed-point sums
+# ---------------------------------------------------------------------------------------------------
+DEFERRED = [
+    ("meshes.hexray", hx.overlay_text(320, 240, want_aa=False), dict(mode=hx.MODE_SINGLE)),                       # one Reflection layer (the heart)
+    ("meshes.hexray", hx.overlay_text(320, 240), dict(mode=hx.MODE_ADAPTIVE_AA)),                                  # two rounds of render -> continue -> resolve
+    ("meshes.hexray", hx.overlay_text(240, 180, dof=True, num_samples=16), dict()),                                # the headline mode
+    ("meshes.hexray", hx.overlay_text(96, 72, dof=True, num_samples=96), dict(seed=9)),                            # several rounds of samples per lane
+    ("meshes.hexray", hx.overlay_text(240, 180, want_aa=False, extra="Node heartNode {\nshader glass\n}\n"), dict(mode=hx.MODE_SINGLE)),   # two rays per hit
+    ("simple.hexray", hx.overlay_text(320, 180), dict(mode=hx.MODE_SINGLE)),
+]
+
+
+@pytest.mark.parametrize("scene,ov,fp", DEFERRED)
+def test_deferred_secondary_rays_match_oracle(gpu, scene, ov, fp):
+    hs = hx.HostScene(scene_path(scene), ov)
+    ds = hx.DeviceScene(hs, deferred_rays=True)
+    g = ds.render(hx.frame_params(collect_counters=True, **fp))
+    gc = ds.counters()
+    t = ds.frame_timing()
+    again = ds.render(hx.frame_params(**fp))
+    tiled = ds.render(hx.frame_params(tile_size=16, **fp))
+    o, oc = oracle_render(hs, hx.frame_params(**fp))
+    assert np.all(rms(g, o) <= RMS_BAR), rms(g, o)
+    assert np.abs(g - o).max() < 5e-3
+    for k in EXACT_COUNTERS:
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    # integer accumulation: the frame does not depend on the order in which waves finish, on the counted build or on the tile order
+    assert np.array_equal(g, again) and np.array_equal(g, tiled)
+    in_place = hx.DeviceScene(hs).render(hx.frame_params(**fp))
+    assert np.abs(g - in_place).max() < 1e-4                        # same rays, another summation order
+    if "simple" not in scene:
+        assert t["deferred_rays"] > 0 and t["continue_ms"] > 0       # and the queue really was used
+    ds.close()
+
+
+def test_deferred_rays_sharded_assembly(gpu):
+    """Four shards of an adaptive-AA frame rendered with deferred secondary rays (halo pixels resolve too) assemble to the whole frame."""
+    import torch
+    from hexray_amd.distributed import padded_tiles_per_rank
+    W, H, world, tile = 320, 200, 4, 16
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(W, H))
+    fp = dict(mode=hx.MODE_ADAPTIVE_AA)
+    ds = hx.DeviceScene(hs, deferred_rays=True)
+    whole = ds.render(hx.frame_params(**fp))
+    slots = padded_tiles_per_rank(W, H, tile, world)
+    st = torch.cuda.current_stream().cuda_stream
+    parts = []
+    for rank in range(world):
+        p = hx.frame_params(tile_size=tile, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES, **fp)
+        buf = torch.zeros(slots * tile * tile * 3, dtype=torch.float32, device="cuda")
+        ds.render_device(p, buf.data_ptr(), 0, st)
+        parts.append(buf)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    p0 = hx.frame_params(tile_size=tile, shard_rank=0, shard_count=world, layout=hx.LAYOUT_TILES, **fp)
+    ds.assemble_frame(p0, torch.cat(parts).data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), whole)
+    ds.close()

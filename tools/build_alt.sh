@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build an alternative libhexray_hip_<tag>.so with extra compiler defines, for an A/B inside one gpurun call (tools/ab2.sh).
+# usage: tools/build_alt.sh <tag> [-DNAME=VALUE ...]
+set -e
+cd "$(dirname "$0")/.."
+tag=$1; shift
+mkdir -p build/alt_$tag
+HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -Ihexray_amd/csrc $*"
+hipcc $HIPFLAGS -O2 -mllvm -amdgpu-sched-strategy=max-ilp -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
+p1=$!
+hipcc $HIPFLAGS -O2 -c -o build/alt_$tag/hf.o hexray_amd/csrc/hxr_kernels_heightfield.hip &
+p2=$!
+hipcc $HIPFLAGS -O2 -mllvm -amdgpu-sched-strategy=max-ilp -c -o build/alt_$tag/mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
+p3=$!
+hipcc $HIPFLAGS -O3 -c -o build/alt_$tag/api.o hexray_amd/csrc/hxr_api.hip
+wait $p1; wait $p2; wait $p3
+hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip_$tag.so build/alt_$tag/api.o build/alt_$tag/mesh.o build/alt_$tag/mesh2.o build/alt_$tag/hf.o
+echo built hexray_amd/lib/libhexray_hip_$tag.so
