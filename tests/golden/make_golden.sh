@@ -4,4 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 make -s -C oracle ref
 oracle/_ref/ref_harness > tests/golden/reference_vectors.json
-python3 -c "import json; d=json.load(open('tests/golden/reference_vectors.json')); print({k:(len(v) if isinstance(v,list) else v) for k,v in d.items()})"
+oracle/_ref/ref_harness_shading > tests/golden/reference_shading_vectors.json
+for f in reference_vectors reference_shading_vectors; do
+python3 -c "import json; d=json.load(open('tests/golden/$f.json')); print({k:(len(v) if isinstance(v,list) else v) for k,v in d.items()})"
+done

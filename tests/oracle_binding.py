@@ -12,6 +12,12 @@ ORACLE_LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
 _lib = None
 
 
+class ProbeHit(ctypes.Structure):
+    """hxo_probe_hit (oracle/hxo_oracle.c): the fields of IntersectionInfo a shader or texture reads."""
+
+    _fields_ = [("ip", c_double * 3), ("norm", c_double * 3), ("dNdx", c_double * 3), ("dNdy", c_double * 3), ("u", c_double), ("v", c_double)]
+
+
 def oracle_lib(path=None):
     global _lib
     if path is not None:
@@ -37,6 +43,16 @@ def _load(path):
     lib.hxo_camera_ray.argtypes = [c_void_p, c_int, c_int, c_double, c_double, c_int, c_double, c_double, POINTER(c_double)]
     lib.hxo_philox_words.argtypes = [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32)]
     lib.hxo_max_threads.restype = c_int
+    # unit-level probes of the shading members (tests/test_golden_shading.py)
+    lib.hxo_box_split.argtypes = [POINTER(c_double), POINTER(c_double), c_int, c_double, POINTER(c_double)]
+    lib.hxo_hemisphere.argtypes = [c_double, c_double, POINTER(c_double), POINTER(c_double)]
+    lib.hxo_disk_map.argtypes = [c_double, c_double, POINTER(c_double)]
+    lib.hxo_glossy_dir.argtypes = [POINTER(c_double), POINTER(c_double), c_float, c_double, c_double, POINTER(c_double)]
+    lib.hxo_texture_sample.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(ProbeHit), POINTER(c_float)]
+    lib.hxo_texture_bump.argtypes = [c_void_p, c_int, POINTER(ProbeHit)]
+    lib.hxo_shade_probe.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_double), c_int, c_uint32, POINTER(ProbeHit), POINTER(c_float), POINTER(c_double), c_int]
+    lib.hxo_brdf_eval.argtypes = [c_void_p, c_int, POINTER(ProbeHit), POINTER(c_double), POINTER(c_double), POINTER(c_float)]
+    lib.hxo_brdf_spawn.argtypes = [c_void_p, c_int, POINTER(ProbeHit), POINTER(c_double), POINTER(c_double), c_int, c_uint32, POINTER(c_double), POINTER(c_float), POINTER(c_float)]
     return lib
 
 

@@ -458,3 +458,97 @@ def test_deferred_rays_sharded_assembly(gpu):
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy(), whole)
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# One micro-frame per shader / texture class: the members tests/test_golden_shading.py pins the ORACLE against the reference's
+# own shading.cpp for, here GPU against oracle, each on a scene where that class makes most of the picture
+# ---------------------------------------------------------------------------------------------------
+MICRO_COMMON = """
+PointLight sun {
+	pos (6, 9, -7)
+	color (1, 0.95, 0.9)
+	power 260
+}
+Plane floor {
+	y -1
+	limit 40
+}
+CheckerTexture tiles {
+	color1 (0.8, 0.8, 0.7)
+	color2 (0.1, 0.15, 0.3)
+	scaling 0.9
+}
+Lambert tiled {
+	texture tiles
+}
+Phong shiny {
+	color (0.7, 0.2, 0.2)
+	exponent 60
+}
+Reflection mirror {
+	reflColor (0.9, 0.85, 0.8)
+}
+Refraction water {
+	refrColor (0.9, 0.95, 0.9)
+	ior 1.4
+}
+Fresnel rim {
+	ior 1.4
+}
+Bumps ripples {
+	strength 6
+}
+Const flat {
+	color (0.3, 0.6, 0.2)
+}
+Layered glass {
+	layer water (1, 1, 1)
+	layer mirror (1, 1, 1) rim
+}
+Layered coated {
+	layer shiny (1, 1, 1)
+	layer mirror (0.25, 0.25, 0.3)
+	layer flat (0.1, 0.1, 0.1) tiles
+}
+Sphere lens {
+	O (2.2, 0.3, 1)
+	R 1.3
+}
+"""
+
+
+def micro(ball_shader, floor_shader="tiled", floor_bump=None, lens_shader=None):
+    text = MICRO_COMMON + "Node floorNode {\n\tgeometry floor\n\tshader %s\n%s}\n" % (floor_shader, "\tbump %s\n" % floor_bump if floor_bump else "")
+    text += "Node ball {\n\tgeometry unit\n\tshader %s\n\tscale (1.2, 1, 1.1)\n\trotate (20, 10, 0)\n}\n" % ball_shader
+    if lens_shader:
+        text += "Node lensNode {\n\tgeometry lens\n\tshader %s\n}\n" % lens_shader
+    return hx.overlay_text(96, 72, want_aa=False) + text
+
+
+MICRO_FRAMES = [
+    ("lambert + checker", micro("tiled")),
+    ("phong", micro("shiny")),
+    ("const", micro("flat")),
+    ("reflection", micro("mirror", lens_shader="mirror")),          # two mirrors facing each other: chains up to maxTraceDepth
+    ("refraction", micro("water")),
+    ("fresnel glass (layered)", micro("glass", lens_shader="glass")),
+    ("layered coat", micro("coated", floor_shader="coated")),
+    ("bumps", micro("shiny", floor_shader="mirror", floor_bump="ripples")),
+]
+
+
+@pytest.mark.parametrize("what,text", MICRO_FRAMES, ids=[m[0] for m in MICRO_FRAMES])
+def test_micro_frame_per_shader_class(gpu, what, text):
+    hs = hx.HostScene(scene_path("../tests/golden/tiny.hexray"), text)
+    o, oc = oracle_render(hs, hx.frame_params(mode=hx.MODE_SINGLE))
+    for deferred in (False, True):                                   # sphere scenes run the catch-all kernel either way; the option must be harmless
+        ds = hx.DeviceScene(hs, deferred_rays=deferred)
+        g = ds.render(hx.frame_params(mode=hx.MODE_SINGLE, collect_counters=True))
+        gc = ds.counters()
+        assert np.all(rms(g, o) <= RMS_BAR), (what, rms(g, o))
+        assert np.abs(g - o).max() < 5e-3, what
+        for k in ("camera_samples", "raycasts", "shadow_queries", "node_tests"):
+            assert gc[k] == oc[k], (what, k, gc[k], oc[k])
+        ds.close()
+    assert o.std() > 0.02                                            # a picture, not a blank frame
