@@ -14,6 +14,11 @@ Rank 0 prints one JSON line.  `roofline.achieved` is algorithmic bytes per launc
 formula over the frame's own work counters) divided by the render kernel's mean duration measured with HIP
 events on the launch stream; `cpu_baseline` times the CPU oracle (test infrastructure, a port of the
 reference's algorithm) on this host's cores for the same frame, N = 1 only.
+
+What `value` is and is not: the timed frames are steady-state re-renders of the same frame into a device buffer -- from the
+second frame on the packet schedule is seeded by the previous frame's per-packet clocks.  `other_timings`
+carries what that leaves out: the FIRST frame of a fresh scene handle (no cost map; what a one-shot render() gets), the steady
+state with the adaptive schedule switched off, and frames through hxr_render(), which add the copy to a host buffer.
 """
 import argparse
 import json
@@ -182,6 +187,10 @@ def main():
         if not same:
             raise SystemExit("sharded frame differs from the single-GPU frame")
 
+    other = None
+    if world == 1 and rank == 0:
+        other = other_timings(hx, hs, accel, W, H, stream, torch, np, min(args.steps, 10))
+
     result = None
     if rank == 0:
         value = samples_per_frame * args.steps / elapsed / 1e6
@@ -197,7 +206,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "scene asset data/%s shipped with the reference (no external dataset)" % scene_name,
+            "data": "scene asset data/%s shipped with the reference (no external dataset); Monte-Carlo modes: frames agree with the CPU oracle run on the same "
+                    "counter-based generator, agreement with the reference's own mt19937 statistics is not verifiable here (DESIGN.md section 4)" % scene_name,
             "config": {"workload": description, "width": W, "height": H, "spp": spp if spp > 0 else 1, "tile_size": TILE if world == 1 else SHARD_TILE,
                        "accel": "reference kd-tree (as handed over by the host)" if accel == hx.ACCEL_REFERENCE else "SAH kd-tree rebuilt by the module",
                        "parallelism": "tile-shard x%d, one RCCL gather" % world if world > 1 else "single GPU", "rng_seed": int(probe.rng_seed)},
@@ -217,12 +227,20 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "bytes_per_sample": round(abytes / samples_per_frame, 2),
                 "kernel": "hxr_render_kernel<false>", "kernel_ms": round(kernel_ms_mean, 4),
+                # the algorithmic bytes are served by the scalar cache / L2 / Infinity Cache: what HBM itself moves is `traffic`
+                "hbm_measured_frac": round(traffic / (kernel_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "note": "frac prices the ALGORITHMIC bytes (SURVEY.md 8d) against HBM peak and can exceed what HBM moves: the tables live in cache.  "
+                        "hbm_measured_frac = PMC traffic / kernel time / peak; `compute` (PMC, profiles/) is the roofline that binds: instruction issue.",
+                "compute": compute_roofline(args.workload),
             }
             result["rays_per_sample"] = round(rays / counters["camera_samples"], 3)
             result["Mrays_per_s"] = round(rays / (kernel_ms_mean * 1e-3) / 1e6, 1)
         else:
             result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                   "kernel_ms": round(kernel_ms_mean, 4), "note": "per-rank kernel time of rank 0; counters are collected at N=1 only"}
+        if other is not None:
+            result["other_timings"] = other
+            result["value_is"] = "steady-state frames (schedule seeded by the previous identical frame), device buffer; see other_timings for a first frame and host-buffer frames"
         # outside the timed region, reported separately: scene preparation
         result["scene_prep_s"] = {"host_parse_kd_build_flatten": round(host_prep_s, 3), "hxr_scene_create": round(device_prep_s, 3)}
         if world == 1 and accel == hx.ACCEL_REFERENCE and not args.no_sah_side:
@@ -251,6 +269,66 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def other_timings(hx, hs, accel, W, H, stream, torch, np, frames):
+    """What `value` leaves out (N = 1): a first frame without history, the steady state without the adaptive schedule, and
+    host-buffer frames through hxr_render() (the entry INTEGRATION.md tells a host to call)."""
+    out = {}
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    params = hx.frame_params(tile_size=TILE)
+    first = []
+    for _ in range(3):                     # three fresh scene handles: kernels are loaded, buffers are not, no cost map exists
+        cold = hx.DeviceScene(hs, accel=accel)
+        cold.render_device(params, frame.data_ptr(), W * 12, stream)
+        torch.cuda.synchronize()
+        first.append(cold.last_kernel_ms())
+        cold.close()
+    out["first_frame_kernel_ms"] = round(float(np.median(first)), 4)
+    plain = hx.DeviceScene(hs, accel=accel, adaptive_schedule=False)
+    ms = []
+    for i in range(2 + frames):
+        plain.render_device(params, frame.data_ptr(), W * 12, stream)
+        torch.cuda.synchronize()
+        if i >= 2:
+            ms.append(plain.last_kernel_ms())
+    out["no_adaptive_schedule_kernel_ms"] = round(float(np.mean(ms)), 4)
+    plain.close()
+    warm = hx.DeviceScene(hs, accel=accel)
+    for _ in range(3):
+        warm.render(params)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        warm.render(params)                # blocking: kernel + 24.9 MB copy into a host array per frame
+    out["host_buffer_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+    out["host_buffer_kernel_ms"] = round(float(warm.last_kernel_ms()), 4)
+    warm.close()
+    # the same frames with secondary rays deferred to the continuation pass (hxr_scene_options.deferred_rays)
+    try:
+        dq = hx.DeviceScene(hs, accel=accel, deferred_rays=True)
+        rows = []
+        for i in range(2 + min(frames, 5)):
+            dq.render_device(params, frame.data_ptr(), W * 12, stream)
+            torch.cuda.synchronize()
+            if i >= 2:
+                rows.append(dq.frame_timing())
+        if rows and rows[-1]["deferred_rays"] > 0:
+            out["deferred_rays"] = {k: round(float(np.mean([r[k] for r in rows])), 4) for k in ("total_ms", "render_ms", "continue_ms", "resolve_ms")}
+            out["deferred_rays"]["rays"] = rows[-1]["deferred_rays"]
+        dq.close()
+    except hx.HipError:
+        pass
+    return out
+
+
+def compute_roofline(workload):
+    """The roofline that binds (secondary): vector-ALU issue.  From the committed PMC summary of the same workload
+    (profiles/pmc_compute.json, written by tools/pmc_summary.py from separate rocprofv3 --pmc passes); null when there is none."""
+    path = os.path.join(ROOT, "profiles", "pmc_compute.json")
+    try:
+        return json.load(open(path)).get(workload)
+    except Exception:
+        return None
 
 
 def usable_cpus():

@@ -263,6 +263,14 @@ def hip_lib():
         lib.hxr_last_kernel_ms.restype = c_double
         lib.hxr_last_kernel_ms.argtypes = [c_void_p]
         lib.hxr_get_frame_timing.argtypes = [c_void_p, POINTER(FrameTiming)]
+        lib.hxr_group_create.restype = c_void_p
+        lib.hxr_group_create.argtypes = [c_void_p, POINTER(SceneOptions), POINTER(c_int), c_int]
+        lib.hxr_group_update_camera.argtypes = [c_void_p, c_void_p]
+        lib.hxr_group_render.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
+        lib.hxr_group_last_ms.restype = c_double
+        lib.hxr_group_last_ms.argtypes = [c_void_p, POINTER(c_double)]
+        lib.hxr_group_size.argtypes = [c_void_p]
+        lib.hxr_group_destroy.argtypes = [c_void_p]
         lib.hxr_scene_destroy.argtypes = [c_void_p]
         lib.hxr_last_error.restype = c_char_p
         _hip = lib
@@ -271,6 +279,13 @@ def hip_lib():
 
 class HipError(RuntimeError):
     pass
+
+
+class Cancelled(RuntimeError):
+    """hxr_render / hxr_group_render returned HXR_CANCELLED: the caller's flag was raised, the frame is incomplete."""
+
+
+PROGRESS_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int)   # hxr_progress_cb
 
 
 def _check(code: int, what: str):
@@ -322,12 +337,17 @@ class DeviceScene:
         s = self.host.settings
         return (params.width or s.frame_width, params.height or s.frame_height)
 
-    def render(self, params: FrameParams | None = None) -> np.ndarray:
-        """Blocking render into a host float32 array of shape (H, W, 3): the reference's vfb."""
+    def render(self, params: FrameParams | None = None, cancel=None, on_tile=None, out: np.ndarray | None = None) -> np.ndarray:
+        """Blocking render into a host float32 array of shape (H, W, 3): the reference's vfb.  ``cancel``: a ctypes.c_int the
+        caller may raise from another thread (the call then raises Cancelled); ``on_tile(x0, y0, x1, y1)``: progress callback."""
         params = params or frame_params()
         w, h = self.frame_size(params)
-        out = np.zeros((h, w, 3), dtype=np.float32)
-        _check(hip_lib().hxr_render(self._s, ctypes.byref(params), out.ctypes.data, w * 12, None, None, None), "hxr_render")
+        if out is None:
+            out = np.zeros((h, w, 3), dtype=np.float32)
+        cb = PROGRESS_CB(lambda user, x0, y0, x1, y1: on_tile(x0, y0, x1, y1)) if on_tile else None
+        rc = _check(hip_lib().hxr_render(self._s, ctypes.byref(params), out.ctypes.data, w * 12, ctypes.byref(cancel) if cancel is not None else None, cb, None), "hxr_render")
+        if rc == 1:
+            raise Cancelled("hxr_render: cancelled")
         return out
 
     def render_device(self, params: FrameParams, d_out: int, row_stride_bytes: int, stream: int = 0):
@@ -374,6 +394,54 @@ class DeviceScene:
         if getattr(self, "_s", None):
             hip_lib().hxr_scene_destroy(self._s)
             self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceGroup:
+    """One process, several GPUs (hxr_group_*): the frame's tiles are dealt round-robin to the devices, gathered with
+    peer-to-peer copies and assembled on the first one.  A device id may be listed more than once."""
+
+    def __init__(self, host_scene: HostScene, devices, accel: int = 0, adaptive_schedule: bool = True, deferred_rays: bool = False):
+        opt = SceneOptions(ctypes.sizeof(SceneOptions), accel, 0 if adaptive_schedule else 1, 1 if deferred_rays else 0)
+        ids = (c_int * len(devices))(*devices)
+        self._g = hip_lib().hxr_group_create(host_scene.desc, ctypes.byref(opt), ids, len(devices))
+        if not self._g:
+            raise HipError("hxr_group_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))
+        self.host = host_scene
+        global _initialised_device
+        _initialised_device = devices[0]
+
+    def render(self, params: FrameParams | None = None, cancel=None, on_tile=None) -> np.ndarray:
+        params = params or frame_params()
+        s = self.host.settings
+        w, h = params.width or s.frame_width, params.height or s.frame_height
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        cb = PROGRESS_CB(lambda user, x0, y0, x1, y1: on_tile(x0, y0, x1, y1)) if on_tile else None
+        rc = _check(hip_lib().hxr_group_render(self._g, ctypes.byref(params), out.ctypes.data, w * 12, ctypes.byref(cancel) if cancel is not None else None, cb, None),
+                    "hxr_group_render")
+        if rc == 1:
+            raise Cancelled("hxr_group_render: cancelled")
+        return out
+
+    def last_ms(self):
+        n = hip_lib().hxr_group_size(self._g)
+        each = (c_double * n)()
+        total = hip_lib().hxr_group_last_ms(self._g, each)
+        return total, list(each)
+
+    def update_camera(self):
+        cam_addr = ctypes.addressof(SceneDescHeader.from_address(self.host.desc).camera)
+        _check(hip_lib().hxr_group_update_camera(self._g, cam_addr), "hxr_group_update_camera")
+
+    def close(self):
+        if getattr(self, "_g", None):
+            hip_lib().hxr_group_destroy(self._g)
+            self._g = None
 
     def __del__(self):
         try:

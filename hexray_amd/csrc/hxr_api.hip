@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <ctime>
 #include <string>
 #include <vector>
 #include "hexray_hip.h"
@@ -112,6 +113,17 @@ struct hxr_scene {
 	uint32_t* d_qctl = nullptr;         // two control blocks (pass 1 / Monte-Carlo, pass 3) of QCTL_WORDS words
 	long long* d_accum = nullptr;       size_t accum_bytes = 0;
 	bool accum_dirty = false;           // a frame stopped between the continuation pass and the resolve
+	// hxr_render() with a cancel flag or a progress callback: the frame runs on `main_stream` while the calling thread watches
+	// the caller's flag and the per-tile pixel counts through `aux_stream`
+	hipStream_t main_stream = nullptr, aux_stream = nullptr;
+	uint32_t* d_watch = nullptr;        size_t watch_words = 0;   // [0] cancel word, [16 ...] pixels written per shard tile
+	uint32_t* h_watch = nullptr;                                  // pinned host copy of the tile counts
+	uint32_t* h_cancel = nullptr;                                 // the cancel word: pinned host memory mapped into the device ...
+	uint32_t* d_cancel = nullptr;                                 // ... and its device-side address
+	hipEvent_t ev_done = nullptr;
+	const uint32_t* watch_cancel = nullptr;                       // what the next render_on_stream puts into HxrLaunch (null: nothing watched)
+	uint32_t* watch_tiles = nullptr;
+	int device = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	hipEvent_t ev_pass[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per pass: before render, after render, after continuation, after resolve
 	int passes_timed = 0;
@@ -346,6 +358,8 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 	L.tile_size = p.tile; L.tiles_x = p.tiles_x; L.tiles_y = p.tiles_y;
 	L.shard_rank = p.rank; L.shard_count = p.count; L.num_shard_tiles = p.ntiles;
 	L.aa_count = (const int32_t*)(s->d_work + 512);
+	L.cancel = s->watch_cancel;
+	L.tile_done = s->watch_tiles;
 }
 
 int grid_for(uint32_t chunks)
@@ -596,6 +610,16 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	return 0;
 }
 
+int ensure_cancel_word(hxr_scene* s)
+{
+	if (!s->h_cancel) {
+		HIP_TRY(hipHostMalloc((void**)&s->h_cancel, 64, hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void**)&s->d_cancel, s->h_cancel, 0));
+	}
+	__atomic_store_n(s->h_cancel, 0u, __ATOMIC_SEQ_CST);
+	return 0;
+}
+
 int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, size_t stride, hipStream_t st)
 {
 	Plan p;
@@ -722,6 +746,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	L3.pixels_per_chunk = 8;
 	if (const char* e = getenv("HXR_AA_PPC")) L3.pixels_per_chunk = atoi(e);   // developer aid
 	L3.num_extra_pixels = 0;
+	L3.tile_done = nullptr;
 	L3.aa_list = s->d_aa_list;
 	L3.sched_cost = nullptr;
 	L3.sched_flags = nullptr;
@@ -787,6 +812,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	const bool adaptive = !(opt && opt->no_adaptive_schedule) && !getenv("HXR_NO_ADAPTIVE_SCHEDULE");
 	hxr_scene* s = new hxr_scene;
 	s->adaptive = adaptive;
+	s->device = g_device;
 	s->defer_allowed = ((opt && opt->deferred_rays) || getenv("HXR_DEFER")) && !getenv("HXR_NO_DEFER");
 	for (int64_t i = 0; i < d->num_nodes; i++) {   // validate() has bounded this walk
 		int rays = 0, pending = 1;
@@ -1018,6 +1044,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 int hxr_scene_update_camera(hxr_scene* s, const hxr_camera* cam)
 {
 	if (!s || !cam) { set_err("null argument"); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(s->device));
 	s->camera = *cam;
 	s->host_view.camera = *cam;
 	HIP_TRY(hipMemcpy((char*)s->dev + offsetof(HxrSceneDev, camera), cam, sizeof *cam, hipMemcpyHostToDevice));
@@ -1056,6 +1083,7 @@ int hxr_shard_tile_rect(const hxr_scene* s, const hxr_frame_params* fp, int i, i
 int hxr_render_device(hxr_scene* s, const hxr_frame_params* fp, float* d_out, size_t row_stride_bytes, void* hip_stream)
 {
 	if (!s || !fp || !d_out) { set_err("null argument"); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(s->device));
 	return render_on_stream(s, fp, d_out, row_stride_bytes, (hipStream_t)hip_stream);
 }
 
@@ -1068,27 +1096,123 @@ int hxr_render(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_
 	if (rc) return rc;
 	if (p.layout != HXR_LAYOUT_FRAME) { set_err("hxr_render writes FRAME layout only"); return HXR_E_INVALID; }
 	if (cancel && *cancel) return HXR_CANCELLED;
+	HIP_TRY(hipSetDevice(s->device));
 	size_t dstride = (size_t)p.W * 12;
 	rc = ensure((void**)&s->d_frame, &s->frame_bytes, dstride * p.H);
 	if (rc) return rc;
-	if (p.count > 1) HIP_TRY(hipMemsetAsync(s->d_frame, 0, dstride * p.H, nullptr));
-	rc = render_on_stream(s, fp, s->d_frame, dstride, nullptr);
+	auto check_queue = [&]() -> int {
+		for (int pass = 0; pass < s->passes_timed; pass++)
+			if (s->pass_deferred[pass]) {   // cannot happen (the queue is sized for the worst case); a frame with dropped rays must not pass silently
+				uint32_t overflow = 0;
+				HIP_TRY(hipMemcpy(&overflow, s->d_qctl + (size_t)pass * QCTL_WORDS + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE, sizeof overflow, hipMemcpyDeviceToHost));
+				if (overflow) { set_err("the deferred-ray queue overflowed"); return HXR_E_HIP; }
+			}
+		return 0;
+	};
+	if (!cancel && !cb) {   // nothing to watch: one stream, one copy
+		if (p.count > 1) HIP_TRY(hipMemsetAsync(s->d_frame, 0, dstride * p.H, nullptr));
+		rc = render_on_stream(s, fp, s->d_frame, dstride, nullptr);
+		if (rc) return rc;
+		HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, s->d_frame, dstride, dstride, p.H, hipMemcpyDeviceToHost));
+		return check_queue();
+	}
+
+	// Watched frame.  The kernels run on a stream of their own; this thread polls the caller's cancel flag (the reference polls
+	// checkForUserExit() per bucket row, src/main.cpp:280,333,370) and the per-tile pixel counts the render kernel keeps
+	// (displayVFBRect per finished bucket, src/main.cpp:312,379), and talks to the GPU through a second stream: raising the device-side
+	// cancel word makes every wavefront stop taking packets, finished tiles are copied out and reported while the rest still renders.
+	if (!s->main_stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&s->main_stream, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+	}
+	const size_t words = 16 + (size_t)std::max(p.ntiles, 1);
+	if (s->watch_words < words) {
+		if (s->d_watch) (void)hipFree(s->d_watch);
+		if (s->h_watch) (void)hipHostFree(s->h_watch);
+		s->d_watch = nullptr; s->h_watch = nullptr; s->watch_words = 0;
+		HIP_TRY(hipMalloc((void**)&s->d_watch, words * sizeof(uint32_t)));
+		HIP_TRY(hipHostMalloc((void**)&s->h_watch, words * sizeof(uint32_t), hipHostMallocDefault));
+		s->watch_words = words;
+	}
+	HIP_TRY(hipMemsetAsync(s->d_watch, 0, words * sizeof(uint32_t), s->main_stream));
+	rc = ensure_cancel_word(s);
 	if (rc) return rc;
-	HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, s->d_frame, dstride, dstride, p.H, hipMemcpyDeviceToHost));
-	for (int pass = 0; pass < s->passes_timed; pass++)
-		if (s->pass_deferred[pass]) {   // cannot happen (the queue is sized for the worst case); a frame with dropped rays must not pass silently
-			uint32_t overflow = 0;
-			HIP_TRY(hipMemcpy(&overflow, s->d_qctl + (size_t)pass * QCTL_WORDS + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE, sizeof overflow, hipMemcpyDeviceToHost));
-			if (overflow) { set_err("the deferred-ray queue overflowed"); return HXR_E_HIP; }
+	if (p.count > 1) HIP_TRY(hipMemsetAsync(s->d_frame, 0, dstride * p.H, s->main_stream));
+	// tiles can be handed over one by one when the render kernel writes final pixels straight into d_frame
+	const bool final_pixels = (p.mode == HXR_MODE_SINGLE || p.mode == HXR_MODE_MONTE_CARLO);
+	s->watch_cancel = cancel ? s->d_cancel : nullptr;
+	s->watch_tiles = cb ? s->d_watch + 16 : nullptr;
+	rc = render_on_stream(s, fp, s->d_frame, dstride, s->main_stream);
+	const bool deferred = s->pass_deferred[0];   // then pixels are final only after the resolve pass
+	s->watch_cancel = nullptr;
+	s->watch_tiles = nullptr;
+	if (rc) return rc;
+	HIP_TRY(hipEventRecord(s->ev_done, s->main_stream));
+	std::vector<char> reported((size_t)p.ntiles, 0);
+	auto tile_rect = [&](int i, int& x0, int& y0, int& x1, int& y1) {
+		int t = i * p.count + p.rank;
+		x0 = (t % p.tiles_x) * p.tile;
+		y0 = (t / p.tiles_x) * p.tile;
+		x1 = std::min(x0 + p.tile, p.W);
+		y1 = std::min(y0 + p.tile, p.H);
+	};
+	auto hand_over = [&](int i) -> int {   // copy one finished tile into the caller's frame and report it
+		int x0, y0, x1, y1;
+		tile_rect(i, x0, y0, x1, y1);
+		HIP_TRY(hipMemcpy2DAsync((char*)vfb + (size_t)y0 * row_stride_bytes + (size_t)x0 * 12, row_stride_bytes, (char*)s->d_frame + (size_t)y0 * dstride + (size_t)x0 * 12,
+		                         dstride, (size_t)(x1 - x0) * 12, (size_t)(y1 - y0), hipMemcpyDeviceToHost, s->aux_stream));
+		HIP_TRY(hipStreamSynchronize(s->aux_stream));
+		reported[(size_t)i] = 1;
+		cb(user, x0, y0, x1, y1);
+		return 0;
+	};
+	bool signalled = false;
+	for (;;) {
+		hipError_t q = hipEventQuery(s->ev_done);
+		if (q == hipSuccess) break;
+		if (q != hipErrorNotReady) { set_err("hipEventQuery failed: %s", hipGetErrorString(q)); return HXR_E_HIP; }
+		if (cancel && *cancel && !signalled) {
+			__atomic_store_n(s->h_cancel, 1u, __ATOMIC_SEQ_CST);   // the waves read this word itself
+			signalled = true;
 		}
-	if (cancel && *cancel) return HXR_CANCELLED;
-	if (cb)
-		for (int i = 0; i < p.ntiles; i++) {
-			int x0, y0, x1, y1;
-			hxr_shard_tile_rect(s, fp, i, &x0, &y0, &x1, &y1);
-			cb(user, x0, y0, x1, y1);
+		if (cb && final_pixels && !deferred && !signalled) {
+			HIP_TRY(hipMemcpyAsync(s->h_watch + 16, s->d_watch + 16, (size_t)p.ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost, s->aux_stream));
+			HIP_TRY(hipStreamSynchronize(s->aux_stream));
+			for (int i = 0; i < p.ntiles; i++) {
+				if (reported[(size_t)i]) continue;
+				int x0, y0, x1, y1;
+				tile_rect(i, x0, y0, x1, y1);
+				if (s->h_watch[16 + i] >= (uint32_t)((x1 - x0) * (y1 - y0))) {
+					rc = hand_over(i);
+					if (rc) return rc;
+				}
+			}
 		}
-	return 0;
+		struct timespec nap = {0, 100 * 1000};   // 0.1 ms between looks
+		nanosleep(&nap, nullptr);
+	}
+	HIP_TRY(hipStreamSynchronize(s->main_stream));
+	if (signalled || (cancel && *cancel)) return HXR_CANCELLED;   // like render() returning false: the frame is incomplete
+	// whatever has not gone out tile by tile (adaptive-AA and deferred frames: everything)
+	bool any_reported = false;
+	for (char r : reported) any_reported = any_reported || r;
+	if (!any_reported) {
+		HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, s->d_frame, dstride, dstride, p.H, hipMemcpyDeviceToHost));
+		if (cb)
+			for (int i = 0; i < p.ntiles; i++) {
+				int x0, y0, x1, y1;
+				tile_rect(i, x0, y0, x1, y1);
+				cb(user, x0, y0, x1, y1);
+			}
+	} else {
+		for (int i = 0; i < p.ntiles; i++)
+			if (!reported[(size_t)i]) {
+				rc = hand_over(i);
+				if (rc) return rc;
+			}
+	}
+	return check_queue();
 }
 
 int hxr_assemble_frame(const hxr_scene* s, const hxr_frame_params* fp, const float* d_gathered, size_t per_rank_bytes, float* d_frame,
@@ -1166,6 +1290,7 @@ int hxr_get_counters(const hxr_scene* s, hxr_counters* out)
 	if (!s || !out) { set_err("null argument"); return HXR_E_INVALID; }
 	memset(out, 0, sizeof *out);
 	if (!s->counters_valid) { set_err("the last frame was rendered without collect_counters"); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipDeviceSynchronize());
 	unsigned long long raw[HC_NUM + PH_NUM];
 	HIP_TRY(hipMemcpy(raw, s->d_counters, sizeof raw, hipMemcpyDeviceToHost));
@@ -1231,6 +1356,7 @@ int hxr_get_frame_timing(const hxr_scene* s, hxr_frame_timing* out)
 void hxr_scene_destroy(hxr_scene* s)
 {
 	if (!s) return;
+	(void)hipSetDevice(s->device);
 	(void)hipDeviceSynchronize();
 	s->arena.release();
 	if (s->d_frame) (void)hipFree(s->d_frame);
@@ -1246,12 +1372,184 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_queue) (void)hipFree(s->d_queue);
 	if (s->d_qctl) (void)hipFree(s->d_qctl);
 	if (s->d_accum) (void)hipFree(s->d_accum);
+	if (s->d_watch) (void)hipFree(s->d_watch);
+	if (s->h_watch) (void)hipHostFree(s->h_watch);
+	if (s->h_cancel) (void)hipHostFree(s->h_cancel);
+	if (s->main_stream) (void)hipStreamDestroy(s->main_stream);
+	if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+	if (s->ev_done) (void)hipEventDestroy(s->ev_done);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
 	for (int pass = 0; pass < 2; pass++)
 		for (int k = 0; k < 4; k++)
 			if (s->ev_pass[pass][k]) (void)hipEventDestroy(s->ev_pass[pass][k]);
 	delete s;
+}
+
+// ------------------------------------------------------------------ one process, several GPUs
+struct hxr_group {
+	std::vector<hxr_scene*> scenes;        // one replica per entry of device_ids
+	std::vector<int> devices;
+	std::vector<hipStream_t> streams;
+	std::vector<hipEvent_t> arrived;       // device d's tiles have landed on the first device
+	std::vector<float*> d_tiles;           // per device: its tile-major shard buffer (entry 0 renders straight into the landing buffer)
+	std::vector<size_t> tiles_bytes;
+	float* d_landing = nullptr;   size_t landing_bytes = 0;   // first device: all shard buffers, rank-major
+	float* d_frame = nullptr;     size_t frame_bytes = 0;     // first device: the assembled frame
+	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+	double last_ms = -1;
+};
+
+int hxr_group_size(const hxr_group* g) { return g ? (int)g->scenes.size() : 0; }
+
+void hxr_group_destroy(hxr_group* g)
+{
+	if (!g) return;
+	for (size_t d = 0; d < g->scenes.size(); d++) {
+		(void)hipSetDevice(g->devices[d]);
+		(void)hipDeviceSynchronize();
+		if (d < g->d_tiles.size() && g->d_tiles[d]) (void)hipFree(g->d_tiles[d]);
+		if (d < g->streams.size() && g->streams[d]) (void)hipStreamDestroy(g->streams[d]);
+		if (d < g->arrived.size() && g->arrived[d]) (void)hipEventDestroy(g->arrived[d]);
+		hxr_scene_destroy(g->scenes[d]);
+	}
+	if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+	if (g->d_landing) (void)hipFree(g->d_landing);
+	if (g->d_frame) (void)hipFree(g->d_frame);
+	if (g->ev_begin) (void)hipEventDestroy(g->ev_begin);
+	if (g->ev_end) (void)hipEventDestroy(g->ev_end);
+	delete g;
+}
+
+hxr_group* hxr_group_create(const hxr_scene_desc* desc, const hxr_scene_options* options, const int* device_ids, int num_devices)
+{
+	if (!device_ids || num_devices <= 0 || num_devices > 64) { set_err("bad device list"); return nullptr; }
+	hxr_group* g = new hxr_group;
+	for (int d = 0; d < num_devices; d++) {
+		if (hxr_init(device_ids[d])) { hxr_group_destroy(g); return nullptr; }   // binds the calling thread to the device and records its size
+		hxr_scene* s = hxr_scene_create_ex(desc, options);
+		if (!s) { hxr_group_destroy(g); return nullptr; }
+		g->scenes.push_back(s);
+		g->devices.push_back(device_ids[d]);
+		hipStream_t st = nullptr;
+		hipEvent_t ev = nullptr;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+			set_err("cannot create the stream of device %d", device_ids[d]);
+			if (st) (void)hipStreamDestroy(st);
+			hxr_group_destroy(g);
+			return nullptr;
+		}
+		g->streams.push_back(st);
+		g->arrived.push_back(ev);
+		g->d_tiles.push_back(nullptr);
+		g->tiles_bytes.push_back(0);
+		if (d > 0 && device_ids[d] != device_ids[0]) {   // direct xGMI copies where the platform allows them (the copy works either way)
+			int can = 0;
+			if (hipDeviceCanAccessPeer(&can, device_ids[d], device_ids[0]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+			(void)hipGetLastError();
+		}
+	}
+	(void)hipSetDevice(device_ids[0]);
+	if (hipEventCreate(&g->ev_begin) != hipSuccess || hipEventCreate(&g->ev_end) != hipSuccess) { set_err("hipEventCreate failed"); hxr_group_destroy(g); return nullptr; }
+	return g;
+}
+
+int hxr_group_update_camera(hxr_group* g, const hxr_camera* cam)
+{
+	if (!g || !cam) { set_err("null argument"); return HXR_E_INVALID; }
+	for (hxr_scene* s : g->scenes) {
+		int rc = hxr_scene_update_camera(s, cam);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+int hxr_group_render(hxr_group* g, const hxr_frame_params* fp, float* vfb, size_t row_stride_bytes, const volatile int* cancel, hxr_progress_cb cb, void* user)
+{
+	if (!g || !fp || !vfb || g->scenes.empty()) { set_err("null argument"); return HXR_E_INVALID; }
+	const int n = (int)g->scenes.size();
+	if (fp->shard_count > 1 || fp->layout != HXR_LAYOUT_FRAME) { set_err("hxr_group_render shards the frame itself: pass an unsharded FRAME-layout request"); return HXR_E_INVALID; }
+	if (cancel && *cancel) return HXR_CANCELLED;
+	hxr_frame_params base = *fp;
+	if (base.tile_size <= 0) base.tile_size = 8;
+	base.shard_count = n;
+	base.layout = HXR_LAYOUT_TILES;
+	Plan p0;
+	base.shard_rank = 0;
+	int rc = resolve(g->scenes[0], &base, p0);
+	if (rc) return rc;
+	const size_t per_rank = (size_t)p0.ntiles * p0.tile * p0.tile * 12;   // rank 0 owns the most tiles: every rank's slot has its size
+	const size_t dstride = (size_t)p0.W * 12;
+	HIP_TRY(hipSetDevice(g->devices[0]));
+	rc = ensure((void**)&g->d_landing, &g->landing_bytes, per_rank * (size_t)n);
+	if (!rc) rc = ensure((void**)&g->d_frame, &g->frame_bytes, dstride * p0.H);
+	if (rc) return rc;
+	// every device renders its shard; devices other than the first then push their buffer into their slot of the landing buffer
+	for (int d = 0; d < n; d++) {
+		hxr_scene* s = g->scenes[d];
+		HIP_TRY(hipSetDevice(g->devices[d]));
+		float* out = g->d_landing;
+		if (d > 0) {
+			rc = ensure((void**)&g->d_tiles[d], &g->tiles_bytes[d], per_rank);
+			if (rc) return rc;
+			out = g->d_tiles[d];
+		}
+		if (cancel) {   // the cancel word of this replica (see hxr_render)
+			rc = ensure_cancel_word(s);
+			if (rc) return rc;
+			s->watch_cancel = s->d_cancel;
+		}
+		if (d == 0) HIP_TRY(hipEventRecord(g->ev_begin, g->streams[0]));
+		hxr_frame_params mine = base;
+		mine.shard_rank = d;
+		rc = render_on_stream(s, &mine, out, 0, g->streams[d]);
+		s->watch_cancel = nullptr;
+		if (rc) return rc;
+		if (d > 0) {
+			HIP_TRY(hipMemcpyPeerAsync((char*)g->d_landing + per_rank * (size_t)d, g->devices[0], g->d_tiles[d], g->devices[d], per_rank, g->streams[d]));
+			HIP_TRY(hipEventRecord(g->arrived[d], g->streams[d]));
+		}
+	}
+	HIP_TRY(hipSetDevice(g->devices[0]));
+	for (int d = 1; d < n; d++) HIP_TRY(hipStreamWaitEvent(g->streams[0], g->arrived[d], 0));
+	rc = hxr_assemble_frame(g->scenes[0], &base, g->d_landing, per_rank, g->d_frame, dstride, g->streams[0]);
+	if (rc) return rc;
+	HIP_TRY(hipEventRecord(g->ev_end, g->streams[0]));
+	bool signalled = false;
+	for (;;) {
+		hipError_t q = hipEventQuery(g->ev_end);
+		if (q == hipSuccess) break;
+		if (q != hipErrorNotReady) { set_err("hipEventQuery failed: %s", hipGetErrorString(q)); return HXR_E_HIP; }
+		if (cancel && *cancel && !signalled) {
+			for (int d = 0; d < n; d++) __atomic_store_n(g->scenes[d]->h_cancel, 1u, __ATOMIC_SEQ_CST);
+			signalled = true;
+		}
+		struct timespec nap = {0, 100 * 1000};
+		nanosleep(&nap, nullptr);
+	}
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, g->ev_begin, g->ev_end));
+	g->last_ms = ms;
+	if (signalled || (cancel && *cancel)) return HXR_CANCELLED;
+	HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, g->d_frame, dstride, dstride, p0.H, hipMemcpyDeviceToHost));
+	if (cb)
+		for (int t = 0; t < p0.tiles_x * p0.tiles_y; t++) {
+			int x0 = (t % p0.tiles_x) * p0.tile, y0 = (t / p0.tiles_x) * p0.tile;
+			cb(user, x0, y0, std::min(x0 + p0.tile, p0.W), std::min(y0 + p0.tile, p0.H));
+		}
+	return 0;
+}
+
+double hxr_group_last_ms(const hxr_group* g, double* per_device_kernel_ms)
+{
+	if (!g) return -1.0;
+	if (per_device_kernel_ms)
+		for (size_t d = 0; d < g->scenes.size(); d++) {
+			(void)hipSetDevice(g->devices[d]);
+			per_device_kernel_ms[d] = hxr_last_kernel_ms(g->scenes[d]);
+		}
+	if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+	return g->last_ms;
 }
 
 const char* hxr_last_error(void) { return g_err; }

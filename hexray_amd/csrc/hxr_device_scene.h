@@ -164,4 +164,7 @@ struct HxrLaunch {
 	long long* q_accum;              // [W * H][3] colour sums in units of 2^-32
 	int32_t lane_stack_entries;      // per-lane-walk continuation kernels: rows of the per-lane stack (deepest tree + 2)
 	int32_t cont_ticket;             // continuation kernels: rays per ticket (0 = 64, a full wave)
+	// hxr_render() with a cancel flag / a progress callback (null otherwise: the asynchronous entry pays nothing for them)
+	const uint32_t* cancel;          // device word the host raises while the frame runs: waves stop taking packets (checkForUserExit, src/sdl.cpp:253)
+	uint32_t* tile_done;             // [shard tile] pixels written so far: a tile whose count reaches its pixel count is finished (displayVFBRect, src/main.cpp:312)
 };

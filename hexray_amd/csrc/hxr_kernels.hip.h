@@ -1862,6 +1862,13 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	const uint32_t listed_a = P.sched_counts ? P.sched_counts[0] : 0u, listed_b = P.sched_counts ? P.sched_counts[1] : 0u;
 	bool listed_left = listed_a + listed_b > 0;
 	for (;;) {
+		if (P.cancel) {   // the host raised the cancel word (hxr_render): no further packets; every wave leaves through the common exit below.
+			// The word lives in pinned HOST memory mapped into the device (a copy engine or blit kernel could starve behind the persistent
+			// waves of this very kernel): a system-scope load, ~2 us, paid only by frames that are watched.
+			uint32_t stop = 0;
+			if (lane == 0) stop = __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			if (__builtin_amdgcn_readfirstlane(stop)) break;
+		}
 		uint32_t single_pixel = 0xffffffffu;   // != ~0: this packet renders only that pixel
 		if (listed_left) {
 			uint32_t t = 0;
@@ -1993,6 +2000,13 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			dst[0] = acc.x;
 			dst[1] = acc.y;
 			dst[2] = acc.z;
+		}
+		if (P.tile_done && in_tile) {   // progress for hxr_render's callback: the pixels of a packet lie in one tile
+			const unsigned long long wrote = hxr_ballot(live && sub == lanes_per_pixel - 1);
+			if (wrote && lane == (int)__builtin_ctzll(wrote)) {
+				__threadfence();   // the pixel stores before the count
+				atomicAdd(P.tile_done + q / (uint32_t)(P.tile_size * P.tile_size), (uint32_t)__popcll(wrote));
+			}
 		}
 		if (scheduled && !part && lane == 0) {   // what this chunk cost (a single pixel stands for its ppc-pixel chunk)
 			unsigned long long dt = (__builtin_readcyclecounter() - packet_t0) * (single ? (unsigned long long)ppc : 1ull);

@@ -18,7 +18,7 @@ static void usage()
 	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
 	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc] [--seed S] [--device D]\n"
 	       "              [--frames N] [--out frame.bmp|frame.raw] [--counters] [--accel reference|sah]\n"
-	       "              [--no-adaptive-schedule]\n");
+	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n");
 }
 
 int main(int argc, char** argv)
@@ -29,6 +29,8 @@ int main(int argc, char** argv)
 	memset(&fp, 0, sizeof fp);
 	fp.rng_seed = 5489;
 	int device = 0, frames = 1;
+	std::vector<int> devices;   // more than one entry: the frame is sharded over them (hxr_group_*)
+	bool progress = false;
 	hxr_scene_options opt;
 	memset(&opt, 0, sizeof opt);
 	opt.struct_size = sizeof opt;
@@ -52,6 +54,11 @@ int main(int argc, char** argv)
 		else if (a == "--counters") fp.collect_counters = 1;
 		else if (a == "--accel") { std::string v = next(); opt.accel = v == "sah" ? HXR_ACCEL_SAH : HXR_ACCEL_REFERENCE; }
 		else if (a == "--no-adaptive-schedule") opt.no_adaptive_schedule = 1;
+		else if (a == "--deferred-rays") opt.deferred_rays = 1;
+		else if (a == "--gpus") { int n = atoi(next()); devices.clear(); for (int k = 0; k < n; k++) devices.push_back(k); }
+		else if (a == "--devices") { std::string v = next(); devices.clear(); for (size_t at = 0; at < v.size();) { devices.push_back(atoi(v.c_str() + at)); size_t c = v.find(',', at); if (c == std::string::npos) break; at = c + 1; } }
+		else if (a == "--tile") fp.tile_size = atoi(next());
+		else if (a == "--progress") progress = true;
 		else if (a == "-h" || a == "--help") { usage(); return 0; }
 		else if (!a.empty() && a[0] != '-') scene = a;
 		else { usage(); return 2; }
@@ -77,19 +84,37 @@ int main(int argc, char** argv)
 		printf("K-d Tree statistics:\n   nodes            : %d\n   leaf nodes       : %d\n   max depth        : %d\n"
 		       "   avg depth        : %.1f\n   avg tris per leaf: %.1f\n", nodes, leaves, depth, avg_depth, avg_tris);
 	}
-	if (hxr_init(device)) { printf("GPU init failed: %s\n", hxr_last_error()); return 1; }
-	auto t0 = std::chrono::steady_clock::now();
-	hxr_scene* ds = hxr_scene_create_ex(d, &opt);
-	if (!ds) { printf("hxr_scene_create_ex failed: %s\n", hxr_last_error()); return 1; }
 	int W = d->settings.frame_width, H = d->settings.frame_height;
 	std::vector<float> vfb((size_t)W * H * 3);
-	int rc = 0;
-	for (int f = 0; f < frames && rc == 0; f++) rc = hxr_render(ds, &fp, vfb.data(), (size_t)W * 12, nullptr, nullptr, nullptr);
+	int rc = 0, tiles_reported = 0;
+	// displayVFBRect's stand-in (src/main.cpp:312): count the tiles as they arrive
+	auto on_tile = [](void* user, int, int, int, int) { ++*(int*)user; };
+	auto t0 = std::chrono::steady_clock::now();
+	hxr_scene* ds = nullptr;
+	hxr_group* group = nullptr;
+	if (devices.size() > 1) {
+		group = hxr_group_create(d, &opt, devices.data(), (int)devices.size());
+		if (!group) { printf("hxr_group_create failed: %s\n", hxr_last_error()); return 1; }
+		for (int f = 0; f < frames && rc == 0; f++) rc = hxr_group_render(group, &fp, vfb.data(), (size_t)W * 12, nullptr, progress ? +on_tile : nullptr, &tiles_reported);
+	} else {
+		if (devices.size() == 1) device = devices[0];
+		if (hxr_init(device)) { printf("GPU init failed: %s\n", hxr_last_error()); return 1; }
+		ds = hxr_scene_create_ex(d, &opt);
+		if (!ds) { printf("hxr_scene_create_ex failed: %s\n", hxr_last_error()); return 1; }
+		for (int f = 0; f < frames && rc == 0; f++) rc = hxr_render(ds, &fp, vfb.data(), (size_t)W * 12, nullptr, progress ? +on_tile : nullptr, &tiles_reported);
+	}
 	auto t1 = std::chrono::steady_clock::now();
-	if (rc < 0) { printf("hxr_render failed: %s\n", hxr_last_error()); return 1; }
+	if (rc < 0) { printf("render failed: %s\n", hxr_last_error()); return 1; }
 	printf("Elapsed time: %.2f seconds.\n", std::chrono::duration<double>(t1 - t0).count());
-	printf("render kernel: %.3f ms (%d x %d)\n", hxr_last_kernel_ms(ds), W, H);
-	if (fp.collect_counters) {
+	if (group) {
+		std::vector<double> each(devices.size());
+		double ms = hxr_group_last_ms(group, each.data());
+		printf("%d devices: %.3f ms to the assembled frame (%d x %d); render kernels:", (int)devices.size(), ms, W, H);
+		for (double e : each) printf(" %.3f", e);
+		printf(" ms\n");
+	} else printf("render kernel: %.3f ms (%d x %d)\n", hxr_last_kernel_ms(ds), W, H);
+	if (progress) printf("tiles reported: %d\n", tiles_reported);
+	if (fp.collect_counters && ds) {
 		hxr_counters k;
 		if (!hxr_get_counters(ds, &k))
 			printf("samples %llu raycasts %llu shadow %llu node tests %llu box tests %llu triangle tests %llu\n", (unsigned long long)k.camera_samples,
@@ -101,7 +126,8 @@ int main(int argc, char** argv)
 		int w = raw ? hxh_save_raw(out.c_str(), vfb.data(), W, H, (size_t)W * 12) : hxh_save_bmp(out.c_str(), vfb.data(), W, H, (size_t)W * 12);
 		if (w) { printf("cannot write %s\n", out.c_str()); return 1; }
 	}
-	hxr_scene_destroy(ds);
+	if (ds) hxr_scene_destroy(ds);
+	if (group) hxr_group_destroy(group);
 	hxh_scene_free(hs);
 	printf("Exited cleanly\n");
 	return 0;

@@ -348,8 +348,15 @@ int hxr_scene_update_camera(hxr_scene* scene, const hxr_camera* camera);
 
 /* Blocking frame render into a HOST buffer.  Replaces render() (src/main.cpp:416-426).
  * `vfb` receives float RGB at byte offset y*row_stride_bytes + x*12 (pass &vfb[0][0], 23040 for the
- * reference's global).  `cancel` may be NULL; when *cancel becomes nonzero the call returns
- * HXR_CANCELLED at the next pass boundary (checkForUserExit, src/sdl.cpp:253).  `cb` may be NULL. */
+ * reference's global).
+ * `cancel` may be NULL.  While the frame runs the calling thread watches *cancel (the reference polls checkForUserExit() once
+ * per bucket row, src/main.cpp:280,333,370); when it becomes nonzero a device-side word is raised, every wavefront stops taking
+ * ray packets (each finishes the 64 samples it holds) and the call returns HXR_CANCELLED with an incomplete frame, like render()
+ * returning false.
+ * `cb` may be NULL.  It is called once per tile (params->tile_size, default 64 like the reference's buckets) from the calling
+ * thread, maps to displayVFBRect(r, vfb) (src/main.cpp:312,340,379): for 1-spp and Monte-Carlo frames AS SOON AS all pixels of
+ * the tile have been written -- the tile is copied into `vfb` first, the rest of the frame is still rendering -- for adaptive-AA
+ * and deferred-ray frames when the whole frame is final. */
 int hxr_render(hxr_scene* scene, const hxr_frame_params* params, float* vfb, size_t row_stride_bytes,
                const volatile int* cancel, hxr_progress_cb cb, void* user);
 
@@ -397,6 +404,25 @@ typedef struct hxr_frame_timing {
 int hxr_get_frame_timing(const hxr_scene* scene, hxr_frame_timing* out);
 
 void hxr_scene_destroy(hxr_scene* scene);
+
+/* ------------------------------------------------------------------ one process, several GPUs
+ * The frame's tiles (params->tile_size, default 8: small tiles spread the expensive image regions over the devices) are dealt
+ * round-robin to the devices, every device renders its tiles from its own replica of the scene, the tile buffers travel to the
+ * first device with one peer-to-peer copy each (xGMI), which assembles the row-major frame and copies it to the host: the
+ * C-level twin of bench.py's one-process-per-GPU RCCL gather for hosts that, like the reference's main() (src/main.cpp:506-526),
+ * are a single process.  The frame is bit-identical to the single-GPU frame for every number of devices.  A device may be
+ * listed more than once (each entry gets its own replica and its own share of the tiles). */
+typedef struct hxr_group hxr_group;
+hxr_group* hxr_group_create(const hxr_scene_desc* desc, const hxr_scene_options* options, const int* device_ids, int num_devices);
+int hxr_group_update_camera(hxr_group* group, const hxr_camera* camera);
+/* Same contract as hxr_render (cancel is honoured by every device; `cb` is called per tile once the frame has been assembled). */
+int hxr_group_render(hxr_group* group, const hxr_frame_params* params, float* vfb, size_t row_stride_bytes,
+                     const volatile int* cancel, hxr_progress_cb cb, void* user);
+/* Wall-clock milliseconds of the last hxr_group_render call from its first launch to the assembled frame on the first device
+ * (the copy to the host excluded); per_device_kernel_ms (may be NULL, num_devices entries) receives each device's render time. */
+double hxr_group_last_ms(const hxr_group* group, double* per_device_kernel_ms);
+int hxr_group_size(const hxr_group* group);
+void hxr_group_destroy(hxr_group* group);
 
 /* Thread-local, never NULL. */
 const char* hxr_last_error(void);

@@ -552,3 +552,51 @@ def test_micro_frame_per_shader_class(gpu, what, text):
             assert gc[k] == oc[k], (what, k, gc[k], oc[k])
         ds.close()
     assert o.std() > 0.02                                            # a picture, not a blank frame
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json's configs at their FULL size against the oracle (it needs about a second per 1080p x 16 spp frame on 16 cores)
+# ---------------------------------------------------------------------------------------------------------
+FULL_SIZE = [
+    ("config2 simple 1spp", "simple.hexray", dict(width=1920, height=1080, want_aa=False), dict(mode=hx.MODE_SINGLE), EXACT_COUNTERS),
+    ("config3b meshes 16spp", "meshes.hexray", dict(width=1920, height=1080, dof=True, num_samples=16), dict(), ("camera_samples",)),
+    ("config4a heightfield aa", "heightfield.hexray", dict(width=1920, height=1080), dict(mode=hx.MODE_ADAPTIVE_AA), ("camera_samples", "hf_calls", "shadow_queries", "aa_pixels")),
+    ("config4b heightfield 16spp", "heightfield.hexray", dict(width=1920, height=1080, dof=True, num_samples=16), dict(), ("camera_samples",)),
+    ("config5 smallpt 16 paths", "smallpt.hexray", dict(width=1920, height=1080, num_paths=16), dict(), ("camera_samples",)),
+]
+
+
+@pytest.mark.parametrize("what,scene,ov,fp,exact", FULL_SIZE, ids=[f[0] for f in FULL_SIZE])
+def test_full_size_config_against_oracle(gpu, what, scene, ov, fp, exact):
+    g, gc, o, oc = both(scene, hx.overlay_text(**ov), fp)
+    assert g.shape == (1080, 1920, 3) and np.isfinite(g).all()
+    assert np.all(rms(g, o) <= RMS_BAR), (what, rms(g, o))
+    assert int((np.abs(g - o).max(axis=2) > 1e-2).sum()) <= 2, what      # no pixel takes another branch (a handful may sit on a rounding edge)
+    for k in exact:
+        assert gc[k] == oc[k], (what, k, gc[k], oc[k])
+    # data-dependent path lengths in the Monte-Carlo modes: a rounding-level difference may flip a cut-off; 1e-5 relative
+    for k in ("raycasts", "shadow_queries", "node_tests"):
+        assert abs(gc[k] - oc[k]) <= max(2, 1e-5 * oc[k]), (what, k, gc[k], oc[k])
+
+
+def test_smallpt_256_paths_accounting_and_determinism(gpu):
+    """Config 5 at its full sample count is minutes of CPU time, so it is checked through properties: every sample is traced
+    (counter), the frame does not depend on the tile size, a 64-path frame of the same generator stream is a noisier estimate of
+    the same image; and at 160x90 -- a size the oracle finishes in seconds -- all 256 paths agree with the oracle, including the
+    mean luminance (energy within 0.5 %)."""
+    hs = hx.HostScene(scene_path("smallpt.hexray"), hx.overlay_text(1920, 1080, num_paths=256))
+    ds = hx.DeviceScene(hs)
+    a = ds.render(hx.frame_params(collect_counters=True))
+    c = ds.counters()
+    assert c["camera_samples"] == 1920 * 1080 * 256 and c["raycasts"] > 5 * c["camera_samples"]
+    b = ds.render(hx.frame_params(tile_size=16))
+    assert np.array_equal(a, b) and np.isfinite(a).all()
+    ds.close()
+    # the same generator stream at 64 paths: a noisier estimate of the same image, closer than a frame with another seed would be at 1/4 of the samples
+    hs64 = hx.HostScene(scene_path("smallpt.hexray"), hx.overlay_text(1920, 1080, num_paths=64))
+    q = hx.DeviceScene(hs64).render()
+    assert 1e-4 < rms(a, q).mean() < 0.1
+    # and at a size the oracle finishes in seconds, all 256 paths
+    g, gc, o, oc = both("smallpt.hexray", hx.overlay_text(160, 90, num_paths=256), dict())
+    assert np.all(rms(g, o) <= RMS_BAR) and gc["camera_samples"] == oc["camera_samples"] == 160 * 90 * 256
+    assert abs(g.mean() - o.mean()) <= 0.005 * o.mean()               # energy: mean luminance within 0.5 % (SURVEY.md 8d, config 5)
