@@ -34,7 +34,7 @@ class FrameParams(ctypes.Structure):
         ("width", c_int32), ("height", c_int32), ("mode", c_int32), ("spp", c_int32),
         ("rng_seed", c_uint64),
         ("tile_size", c_int32), ("shard_rank", c_int32), ("shard_count", c_int32), ("layout", c_int32),
-        ("collect_counters", c_int32), ("reserved_", c_int32 * 5),
+        ("collect_counters", c_int32), ("foveated_radius", c_int32), ("vip_x", c_int32), ("vip_y", c_int32), ("reserved_", c_int32 * 2),
     ]
 
 
@@ -75,8 +75,9 @@ class Counters(ctypes.Structure):
 
 
 def frame_params(width=0, height=0, mode=MODE_AUTO, spp=0, seed=DEFAULT_SEED, tile_size=0, shard_rank=0,
-                 shard_count=1, layout=LAYOUT_FRAME, collect_counters=False) -> FrameParams:
+                 shard_count=1, layout=LAYOUT_FRAME, collect_counters=False, foveated_radius=0, vip=(-100, -100)) -> FrameParams:
     p = FrameParams()
+    p.foveated_radius, p.vip_x, p.vip_y = foveated_radius, vip[0], vip[1]
     p.width, p.height, p.mode, p.spp = width, height, mode, spp
     p.rng_seed = seed
     p.tile_size, p.shard_rank, p.shard_count, p.layout = tile_size, shard_rank, shard_count, layout
@@ -263,6 +264,8 @@ def hip_lib():
         lib.hxr_last_kernel_ms.restype = c_double
         lib.hxr_last_kernel_ms.argtypes = [c_void_p]
         lib.hxr_get_frame_timing.argtypes = [c_void_p, POINTER(FrameTiming)]
+        lib.hxr_interactive_frame.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, POINTER(c_double)]
+        lib.hxr_interactive_float_frame.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t]
         lib.hxr_group_create.restype = c_void_p
         lib.hxr_group_create.argtypes = [c_void_p, POINTER(SceneOptions), POINTER(c_int), c_int]
         lib.hxr_group_update_camera.argtypes = [c_void_p, c_void_p]
@@ -348,6 +351,25 @@ class DeviceScene:
         rc = _check(hip_lib().hxr_render(self._s, ctypes.byref(params), out.ctypes.data, w * 12, ctypes.byref(cancel) if cancel is not None else None, cb, None), "hxr_render")
         if rc == 1:
             raise Cancelled("hxr_render: cancelled")
+        return out
+
+    def interactive_frame(self, params: FrameParams | None = None, update_camera: bool = True, shifts=(16, 8, 0)):
+        """One frame of the interactive loop: camera update, render, conversion to a 32-bit display surface on the GPU.
+        Returns (surface uint32 [H, W], latency in ms)."""
+        params = params or frame_params()
+        w, h = self.frame_size(params)
+        surface = np.zeros((h, w), dtype=np.uint32)
+        cam_addr = ctypes.addressof(SceneDescHeader.from_address(self.host.desc).camera) if update_camera else None
+        ms = c_double()
+        _check(hip_lib().hxr_interactive_frame(self._s, ctypes.byref(params), cam_addr, surface.ctypes.data, w * 4, shifts[0], shifts[1], shifts[2], ctypes.byref(ms)),
+               "hxr_interactive_frame")
+        return surface, ms.value
+
+    def interactive_float_frame(self, params: FrameParams | None = None) -> np.ndarray:
+        params = params or frame_params()
+        w, h = self.frame_size(params)
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        _check(hip_lib().hxr_interactive_float_frame(self._s, ctypes.byref(params), out.ctypes.data, w * 12), "hxr_interactive_float_frame")
         return out
 
     def render_device(self, params: FrameParams, d_out: int, row_stride_bytes: int, stream: int = 0):

@@ -124,6 +124,7 @@ struct hxr_scene {
 	const uint32_t* watch_cancel = nullptr;                       // what the next render_on_stream puts into HxrLaunch (null: nothing watched)
 	uint32_t* watch_tiles = nullptr;
 	int device = 0;
+	uint32_t* d_surface = nullptr;      size_t surface_bytes = 0;   // hxr_interactive_frame: the 32-bit display pixels before they leave
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	hipEvent_t ev_pass[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per pass: before render, after render, after continuation, after resolve
 	int passes_timed = 0;
@@ -309,6 +310,7 @@ int ensure(void** p, size_t* have, size_t need)
 
 struct Plan {   // resolved frame parameters
 	int W, H, mode, spp, tile, tiles_x, tiles_y, rank, count, ntiles, layout;
+	int fovea, vip_x, vip_y;   // foveated rendering (modes SINGLE / ADAPTIVE_AA): radius (0 = off) and point of interest
 	uint64_t seed;
 };
 
@@ -347,6 +349,12 @@ int resolve(const hxr_scene* s, const hxr_frame_params* fp, Plan& p)
 	p.layout = fp->layout;
 	if (p.layout != HXR_LAYOUT_FRAME && p.layout != HXR_LAYOUT_TILES) { set_err("unknown layout"); return HXR_E_INVALID; }
 	p.seed = fp->rng_seed;
+	// renderWithMonteCarlo has no foveated branch (src/main.cpp:347-384): the fields only matter to the other two modes
+	p.fovea = (p.mode == HXR_MODE_SINGLE || p.mode == HXR_MODE_ADAPTIVE_AA) ? fp->foveated_radius : 0;
+	p.vip_x = fp->vip_x;
+	p.vip_y = fp->vip_y;
+	if (p.fovea < 0 || p.fovea > 1000) { set_err("foveated_radius outside 0..1000"); return HXR_E_INVALID; }   // GlobalSettings::fillProperties, src/scene.cpp:764-778
+	if (p.fovea > 0 && p.count > 1) { set_err("foveated frames are not sharded (an interactive, single-GPU mode)"); return HXR_E_UNSUPPORTED; }
 	return 0;
 }
 
@@ -360,6 +368,7 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 	L.aa_count = (const int32_t*)(s->d_work + 512);
 	L.cancel = s->watch_cancel;
 	L.tile_done = s->watch_tiles;
+	L.fov_radius = p.fovea; L.vip_x = p.vip_x; L.vip_y = p.vip_y;
 }
 
 int grid_for(uint32_t chunks)
@@ -660,7 +669,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		L.out_tiles = p.layout == HXR_LAYOUT_TILES;
 		L.work_counter = s->d_work;
 		// (a deferring render kernel has packets of equal length: nothing to schedule)
-		if (s->adaptive && L.num_chunks >= 4096 && !defer_capacity(s, L.num_chunks, L.spp)) {   // small frames have no tail worth scheduling
+		if (s->adaptive && L.num_chunks >= 4096 && !defer_capacity(s, L.num_chunks, L.spp) && p.fovea == 0) {   // small frames have no tail worth scheduling
 			rc = prepare_schedule(s, p, L, tile_pixels, st);
 			if (rc) return rc;
 		}
@@ -706,7 +715,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	// pass 1 records what its 64-pixel chunks cost (same machinery as the adaptive schedule, nothing listed): pass 3 of THIS
 	// frame starts with the flagged pixels of the expensive chunks, one pixel per packet
 	const uint32_t list_capacity = tile_pixels + 64u;
-	const bool cost_aware = s->adaptive && L.num_chunks >= 1024 && !getenv("HXR_AA_NO_COST") && !defer_capacity(s, L.num_chunks, L.spp);
+	const bool cost_aware = s->adaptive && L.num_chunks >= 1024 && !getenv("HXR_AA_NO_COST") && !defer_capacity(s, L.num_chunks, L.spp) && p.fovea == 0;
 	s->aa_cost_aware = cost_aware;
 	if (cost_aware) {
 		rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)L.num_chunks * sizeof(uint32_t));
@@ -1215,6 +1224,59 @@ int hxr_render(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_
 	return check_queue();
 }
 
+int hxr_interactive_frame(hxr_scene* s, const hxr_frame_params* fp, const hxr_camera* cam, uint32_t* surface, size_t pitch_bytes, int rshift, int gshift, int bshift,
+                          double* latency_ms)
+{
+	if (!s || !fp || !surface) { set_err("null argument"); return HXR_E_INVALID; }
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	Plan p;
+	int rc = resolve(s, fp, p);
+	if (rc) return rc;
+	if (p.layout != HXR_LAYOUT_FRAME || p.count > 1) { set_err("the interactive frame is an unsharded FRAME-layout frame"); return HXR_E_INVALID; }
+	if (pitch_bytes < (size_t)p.W * 4 || rshift < 0 || gshift < 0 || bshift < 0 || rshift > 24 || gshift > 24 || bshift > 24) { set_err("bad surface format"); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(s->device));
+	if (!s->main_stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&s->main_stream, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+	}
+	const size_t dstride = (size_t)p.W * 12;
+	rc = ensure((void**)&s->d_frame, &s->frame_bytes, dstride * p.H);
+	if (!rc) rc = ensure((void**)&s->d_surface, &s->surface_bytes, (size_t)p.W * p.H * 4);
+	if (rc) return rc;
+	if (cam) {   // the camera record is the only part of the scene that changes between the frames of the loop
+		s->camera = *cam;
+		s->host_view.camera = *cam;
+		HIP_TRY(hipMemcpyAsync((char*)s->dev + offsetof(HxrSceneDev, camera), &s->camera, sizeof s->camera, hipMemcpyHostToDevice, s->main_stream));
+	}
+	rc = render_on_stream(s, fp, s->d_frame, dstride, s->main_stream);
+	if (rc) return rc;
+	const size_t total = (size_t)p.W * p.H;
+	const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+	hipLaunchKernelGGL(hxr_quantize_rgb32_kernel, dim3(grid), dim3(256), 0, s->main_stream, (const float*)s->d_frame, dstride, p.W, p.H, (const uint8_t*)s->d_lut, rshift, gshift,
+	                   bshift, s->d_surface, (size_t)p.W * 4);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpy2DAsync(surface, pitch_bytes, s->d_surface, (size_t)p.W * 4, (size_t)p.W * 4, (size_t)p.H, hipMemcpyDeviceToHost, s->main_stream));
+	HIP_TRY(hipStreamSynchronize(s->main_stream));
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	if (latency_ms) *latency_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+	return 0;
+}
+
+int hxr_interactive_float_frame(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_stride_bytes)
+{
+	if (!s || !fp || !vfb) { set_err("null argument"); return HXR_E_INVALID; }
+	Plan p;
+	int rc = resolve(s, fp, p);
+	if (rc) return rc;
+	const size_t dstride = (size_t)p.W * 12;
+	if (!s->d_frame || s->frame_bytes < dstride * p.H) { set_err("no interactive frame of this size has been rendered"); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, s->d_frame, dstride, dstride, p.H, hipMemcpyDeviceToHost));
+	return 0;
+}
+
 int hxr_assemble_frame(const hxr_scene* s, const hxr_frame_params* fp, const float* d_gathered, size_t per_rank_bytes, float* d_frame,
                        size_t row_stride_bytes, void* hip_stream)
 {
@@ -1372,6 +1434,7 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_queue) (void)hipFree(s->d_queue);
 	if (s->d_qctl) (void)hipFree(s->d_qctl);
 	if (s->d_accum) (void)hipFree(s->d_accum);
+	if (s->d_surface) (void)hipFree(s->d_surface);
 	if (s->d_watch) (void)hipFree(s->d_watch);
 	if (s->h_watch) (void)hipHostFree(s->h_watch);
 	if (s->h_cancel) (void)hipHostFree(s->h_cancel);

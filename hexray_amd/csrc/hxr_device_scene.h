@@ -167,4 +167,7 @@ struct HxrLaunch {
 	// hxr_render() with a cancel flag / a progress callback (null otherwise: the asynchronous entry pays nothing for them)
 	const uint32_t* cancel;          // device word the host raises while the frame runs: waves stop taking packets (checkForUserExit, src/sdl.cpp:253)
 	uint32_t* tile_done;             // [shard tile] pixels written so far: a tile whose count reaches its pixel count is finished (displayVFBRect, src/main.cpp:312)
+	// foveated rendering (src/main.cpp:284-311): mode 0 fills 8x8 blocks whose centre is farther than fov_radius from (vip_x, vip_y)
+	// with the mean of five rays; the detect kernel only flags pixels inside the radius.  fov_radius 0 = off.
+	int32_t fov_radius, vip_x, vip_y;
 };

@@ -1934,6 +1934,38 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			const uint32_t qs = min(chunk / max(per_shard, 1u), (uint32_t)(HXR_QUEUE_SHARDS - 1));
 			dq = DeferCtx{P.q_records + (size_t)qs * P.q_capacity, P.q_ctl + qs * HXR_SHARD_STRIDE, P.q_ctl + 2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE, P.q_capacity};
 		}
+		if (mode_ == 0 && P.fov_radius > 0 && !listed && chunk * 64u < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size)) {
+			// Foveated pass 1 (src/main.cpp:284-311).  A chunk of this pass IS one of the reference's 8x8 blocks (64 pixels in Morton
+			// order, lane 0 = its top-left pixel).  Far from the point of interest the block gets the mean of five rays, traced by the
+			// first five lanes at COARSE_KERNEL's positions (src/main.cpp:262-268) and added up in the reference's order.
+			const int bx = __builtin_amdgcn_readlane(x, 0), by = __builtin_amdgcn_readlane(y, 0);
+			const int dxc = bx + 4 - P.vip_x, dyc = by + 4 - P.vip_y;
+			if (dxc * dxc + dyc * dyc > P.fov_radius * P.fov_radius && hxr_ballot(live) != 0) {
+				f3 c = mkf(0, 0, 0);
+				if (lane < 5) {
+					const int sx = bx + (lane == 2 ? 4 : ((lane == 1 || lane == 4) ? 6 : 2)), sy = by + (lane < 2 ? 2 : (lane == 2 ? 4 : 6));
+					const RngCtx rcc{P.seed, (uint32_t)(sy * P.W + sx), 0u};
+					c = trace_sample<COUNT, F>(S, P.W, P.H, (double)sx, (double)sy, rcc, stacks, tl, dq);
+				}
+				f3 mean = mkf(__shfl(c.x, 0, 64), __shfl(c.y, 0, 64), __shfl(c.z, 0, 64));
+				for (int j = 1; j < 5; j++) mean = mean + mkf(__shfl(c.x, j, 64), __shfl(c.y, j, 64), __shfl(c.z, j, 64));
+				mean = mean * 0.2f;
+				if (live) {
+					float* dst = out_pixel(P, q, x, y);
+					dst[0] = mean.x;
+					dst[1] = mean.y;
+					dst[2] = mean.z;
+				}
+				if (P.tile_done) {
+					const unsigned long long wrote = hxr_ballot(live);
+					if (wrote && lane == (int)__builtin_ctzll(wrote)) {
+						__threadfence();
+						atomicAdd(P.tile_done + q / (uint32_t)(P.tile_size * P.tile_size), (uint32_t)__popcll(wrote));
+					}
+				}
+				continue;
+			}
+		}
 		f3 sum = mkf(0, 0, 0);
 		if (live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group)) {
 			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
@@ -2286,7 +2318,9 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, c
 	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < ((tile_pixels + 63u) & ~63u); q += gridDim.x * blockDim.x) {
 		int x, y;
 		bool need = false;
-		if (q < tile_pixels && shard_pixel(P, q, x, y)) {
+		// src/main.cpp:201,205: with a fovea only pixels inside it are candidates
+		if (q < tile_pixels && shard_pixel(P, q, x, y) &&
+		    !((x - P.vip_x) * (x - P.vip_x) + (y - P.vip_y) * (y - P.vip_y) > (P.fov_radius > 0 ? P.fov_radius * P.fov_radius : 999666111))) {
 			const float* me = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
 			for (int dy = -1; dy <= 1 && !need; dy++)
 				for (int dx = -1; dx <= 1 && !need; dx++) {
@@ -2359,6 +2393,25 @@ __global__ void hxr_quantize_kernel(const float* __restrict__ frame, size_t stri
 			uint8_t o = v <= 0 ? 0 : (v >= 1 ? 255 : lut[(int)(v * 4096.0f)]);
 			bgr[i * 3 + c] = o;
 		}
+	}
+}
+
+// displayVFB (src/sdl.cpp:79-90): Color::toRGB32 per pixel -- the three 8-bit sRGB channels shifted to where the display surface
+// wants them (src/color.h:84-90) -- into a 32-bit surface with its own pitch
+__global__ void hxr_quantize_rgb32_kernel(const float* __restrict__ frame, size_t stride, int W, int H, const uint8_t* __restrict__ lut, int rshift, int gshift, int bshift,
+                                          uint32_t* pixels, size_t pitch)
+{
+	size_t total = (size_t)W * H;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		int x = (int)(i % W), y = (int)(i / W);
+		const float* p = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
+		uint32_t c[3];
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			float v = p[k];
+			c[k] = v <= 0 ? 0u : (v >= 1 ? 255u : (uint32_t)lut[(int)(v * 4096.0f)]);
+		}
+		((uint32_t*)((char*)pixels + (size_t)y * pitch))[x] = (c[2] << bshift) | (c[1] << gshift) | (c[0] << rshift);
 	}
 }
 #endif   // HXR_RENDER_KERNEL_ONLY

@@ -4,7 +4,9 @@
 // the frame.  The reference opens an SDL window and can only save on F12 (src/sdl.cpp:103-116,201);
 // there is no window here, and W x H / spp / AA can be overridden from the command line (the
 // reference reads them from the scene file only).
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,7 +20,8 @@ static void usage()
 	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
 	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc] [--seed S] [--device D]\n"
 	       "              [--frames N] [--out frame.bmp|frame.raw] [--counters] [--accel reference|sah]\n"
-	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n");
+	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n"
+	       "              [--interactive FRAMES] [--fovea RADIUS]\n");
 }
 
 int main(int argc, char** argv)
@@ -31,6 +34,7 @@ int main(int argc, char** argv)
 	int device = 0, frames = 1;
 	std::vector<int> devices;   // more than one entry: the frame is sharded over them (hxr_group_*)
 	bool progress = false;
+	int interactive_frames = 0;   // > 0: the interactive loop (gameloop(), src/main.cpp:443-504) over a scripted camera path
 	hxr_scene_options opt;
 	memset(&opt, 0, sizeof opt);
 	opt.struct_size = sizeof opt;
@@ -59,6 +63,8 @@ int main(int argc, char** argv)
 		else if (a == "--devices") { std::string v = next(); devices.clear(); for (size_t at = 0; at < v.size();) { devices.push_back(atoi(v.c_str() + at)); size_t c = v.find(',', at); if (c == std::string::npos) break; at = c + 1; } }
 		else if (a == "--tile") fp.tile_size = atoi(next());
 		else if (a == "--progress") progress = true;
+		else if (a == "--interactive") interactive_frames = atoi(next());
+		else if (a == "--fovea") fp.foveated_radius = atoi(next());
 		else if (a == "-h" || a == "--help") { usage(); return 0; }
 		else if (!a.empty() && a[0] != '-') scene = a;
 		else { usage(); return 2; }
@@ -92,7 +98,37 @@ int main(int argc, char** argv)
 	auto t0 = std::chrono::steady_clock::now();
 	hxr_scene* ds = nullptr;
 	hxr_group* group = nullptr;
-	if (devices.size() > 1) {
+	if (interactive_frames > 0) {
+		// The reference's interactive mode without its window: the scene stays in HBM, per frame only the camera record travels, the
+		// frame comes back as the 32-bit pixels of a display surface (XRGB8888: the shifts SDL reports for a desktop window surface).
+		// Keys and mouse are replaced by a fixed path: forward, slowly turning, the point of interest circling the frame centre.
+		if (devices.size() == 1) device = devices[0];
+		if (hxr_init(device)) { printf("GPU init failed: %s\n", hxr_last_error()); return 1; }
+		ds = hxr_scene_create_ex(d, &opt);
+		if (!ds) { printf("hxr_scene_create_ex failed: %s\n", hxr_last_error()); return 1; }
+		if (fp.tile_size <= 0) fp.tile_size = 16;   // getBucketsList(scene.settings.interactive ? 16 : 64), src/main.cpp:515
+		std::vector<uint32_t> surface((size_t)W * H);
+		std::vector<double> lat;
+		auto loop0 = std::chrono::steady_clock::now();
+		for (int f = 0; f < interactive_frames && rc == 0; f++) {
+			hxh_camera_move(hs, 0.0, 0.35);
+			hxh_camera_rotate(hs, 0.4, 0.0);
+			fp.vip_x = W / 2 + (int)(W * 0.25 * cos(f * 0.1));
+			fp.vip_y = H / 2 + (int)(H * 0.25 * sin(f * 0.1));
+			double ms = 0;
+			rc = hxr_interactive_frame(ds, &fp, &hxh_scene_desc(hs)->camera, surface.data(), (size_t)W * 4, 16, 8, 0, &ms);
+			lat.push_back(ms);
+		}
+		auto loop1 = std::chrono::steady_clock::now();
+		if (rc < 0) { printf("hxr_interactive_frame failed: %s\n", hxr_last_error()); return 1; }
+		double total_ms = std::chrono::duration<double, std::milli>(loop1 - loop0).count();
+		printf("%d frames in %.0f ms: %.2f FPS\n", interactive_frames, total_ms, interactive_frames / (total_ms * 0.001));   // the line gameloop() prints
+		std::vector<double> sorted = lat;
+		std::sort(sorted.begin(), sorted.end());
+		printf("frame latency (camera update -> display surface complete): min %.3f ms, median %.3f ms, max %.3f ms (first frame %.3f ms)\n", sorted.front(),
+		       sorted[sorted.size() / 2], sorted.back(), lat.front());
+		rc = hxr_interactive_float_frame(ds, &fp, vfb.data(), (size_t)W * 12);   // the last frame, for --out
+	} else if (devices.size() > 1) {
 		group = hxr_group_create(d, &opt, devices.data(), (int)devices.size());
 		if (!group) { printf("hxr_group_create failed: %s\n", hxr_last_error()); return 1; }
 		for (int f = 0; f < frames && rc == 0; f++) rc = hxr_group_render(group, &fp, vfb.data(), (size_t)W * 12, nullptr, progress ? +on_tile : nullptr, &tiles_reported);

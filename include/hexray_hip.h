@@ -263,7 +263,13 @@ typedef struct hxr_frame_params {
 	int32_t shard_count;      /* 0 or 1 = whole frame */
 	int32_t layout;           /* hxr_output_layout */
 	int32_t collect_counters; /* nonzero: run the instrumented kernel build and fill hxr_get_counters() */
-	int32_t reserved_[5];
+	/* Foveated rendering of renderWithoutMonteCarlo (GlobalSettings::foveatedRadius, src/main.cpp:284-311,203-205; modes SINGLE and
+	 * ADAPTIVE_AA): 8x8 pixel blocks whose centre lies farther than foveated_radius pixels from the point of interest (vip_x, vip_y)
+	 * -- the reference's vipX / vipY, the mouse position; (-100, -100) until the mouse has moved -- are filled with the mean of five
+	 * rays, and only pixels inside the radius are candidates for anti-aliasing.  0 = off (every pixel is traced). */
+	int32_t foveated_radius;
+	int32_t vip_x, vip_y;
+	int32_t reserved_[2];
 } hxr_frame_params;
 
 /* Work counters of the last frame (feeds the algorithmic-bytes formula). */
@@ -384,6 +390,15 @@ int hxr_assemble_frame(const hxr_scene* scene, const hxr_frame_params* params, c
  * src/color.h:36-47,84-90).  DEVICE pointers; `d_bgr` receives B,G,R bytes per pixel, rows top-down. */
 int hxr_quantize_srgb8(const float* d_frame, size_t row_stride_bytes, int width, int height,
                        uint8_t* d_bgr, void* hip_stream);
+
+/* One frame of the interactive loop (gameloop(), src/main.cpp:443-504): Camera::beginFrame's result for this frame (`camera`, NULL =
+ * unchanged), render(false), displayVFB (src/sdl.cpp:79-90) -- the frame is converted on the GPU with Color::toRGB32(rshift, gshift,
+ * bshift) and lands in the caller's 32-bit display surface (`surface` = SDL_Surface::pixels, `pitch_bytes` = SDL_Surface::pitch; any
+ * host memory).  Blocking; *latency_ms (may be NULL) receives the wall-clock time from entry to the surface being complete.  The float
+ * frame of the last call stays in HBM: hxr_interactive_float_frame copies it out (screenshots, tests). */
+int hxr_interactive_frame(hxr_scene* scene, const hxr_frame_params* params, const hxr_camera* camera, uint32_t* surface, size_t pitch_bytes,
+                          int rshift, int gshift, int bshift, double* latency_ms);
+int hxr_interactive_float_frame(hxr_scene* scene, const hxr_frame_params* params, float* vfb, size_t row_stride_bytes);
 
 int hxr_get_counters(const hxr_scene* scene, hxr_counters* out);
 

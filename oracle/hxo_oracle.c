@@ -1195,7 +1195,10 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 #pragma omp critical
 			counters_add(&total, &cx.cnt);
 		}
-	} else { /* renderWithoutMonteCarlo, src/main.cpp:253-345 (foveated branch not restated) */
+	} else { /* renderWithoutMonteCarlo, src/main.cpp:253-345 */
+		const int fovea = fp->foveated_radius, vip_x = fp->vip_x, vip_y = fp->vip_y;
+		const int fovea_thresh = fovea * fovea;
+		static const int coarse[5][2] = {{2, 2}, {2, 6}, {4, 4}, {6, 2}, {6, 6}}; /* COARSE_KERNEL, src/main.cpp:262-268: {dy, dx} */
 #pragma omp parallel
 		{
 			ctx_t cx;
@@ -1205,14 +1208,49 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 			for (int b = 0; b < nb; b++) {
 				int x0 = (b % BW) * B, y0 = (b / BW) * B;
 				int x1 = x0 + B < W ? x0 + B : W, y1 = y0 + B < H ? y0 + B : H;
-				for (int y = y0; y < y1; y++)
-					for (int x = x0; x < x1; x++) {
-						cx.pixel = (uint32_t)(y * W + x);
-						cx.sample = 0;
-						col c = trace_sample(&cx, x, y);
-						float* o = px(out, row_stride_bytes, x, y);
-						o[0] = c.r; o[1] = c.g; o[2] = c.b;
+				if (fovea <= 0) { /* src/main.cpp:277-283 */
+					for (int y = y0; y < y1; y++)
+						for (int x = x0; x < x1; x++) {
+							cx.pixel = (uint32_t)(y * W + x);
+							cx.sample = 0;
+							col c = trace_sample(&cx, x, y);
+							float* o = px(out, row_stride_bytes, x, y);
+							o[0] = c.r; o[1] = c.g; o[2] = c.b;
+						}
+					continue;
+				}
+				/* foveated rendering, src/main.cpp:284-311: 8x8 blocks far from (vipX, vipY) get the mean of five rays */
+				for (int by = y0; by < y1; by += 8) {
+					int bye = by + 8 < y1 ? by + 8 : y1;
+					for (int bx = x0; bx < x1; bx += 8) {
+						int bxe = bx + 8 < x1 ? bx + 8 : x1;
+						int cxp = bx + 4, cyp = by + 4;
+						if ((cxp - vip_x) * (cxp - vip_x) + (cyp - vip_y) * (cyp - vip_y) > fovea_thresh) {
+							col sum = C(0, 0, 0);
+							for (int j = 0; j < 5; j++) {
+								int sx = bx + coarse[j][1], sy = by + coarse[j][0];
+								cx.pixel = (uint32_t)(sy * W + sx);
+								cx.sample = 0;
+								sum = cadd(sum, trace_sample(&cx, sx, sy));
+							}
+							sum = cscale(sum, 0.2f);
+							for (int y = by; y < bye; y++)
+								for (int x = bx; x < bxe; x++) {
+									float* o = px(out, row_stride_bytes, x, y);
+									o[0] = sum.r; o[1] = sum.g; o[2] = sum.b;
+								}
+						} else {
+							for (int y = by; y < bye; y++)
+								for (int x = bx; x < bxe; x++) {
+									cx.pixel = (uint32_t)(y * W + x);
+									cx.sample = 0;
+									col c = trace_sample(&cx, x, y);
+									float* o = px(out, row_stride_bytes, x, y);
+									o[0] = c.r; o[1] = c.g; o[2] = c.b;
+								}
+						}
 					}
+				}
 			}
 #pragma omp critical
 			counters_add(&total, &cx.cnt);
@@ -1227,6 +1265,8 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 				for (int x = 0; x < W; x++) {
 					const float* me = px(out, row_stride_bytes, x, y);
 					int need = 0;
+					/* src/main.cpp:201,205: outside the fovea nothing is anti-aliased */
+					if ((x - vip_x) * (x - vip_x) + (y - vip_y) * (y - vip_y) > (fovea > 0 ? fovea_thresh : 999666111)) { flags[(size_t)y * W + x] = 0; continue; }
 					for (int k = 0; k < 8 && !need; k++) {
 						int nx = x + nb8[k][0], ny = y + nb8[k][1];
 						if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
