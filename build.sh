@@ -12,7 +12,7 @@ mkdir -p hexray_amd/lib hexray_amd/bin
 # host flags = the reference Release flags (CMakeLists.txt:80): the kd builder only reproduces the
 # reference tree bit-for-bit (SURVEY.md 8c(iv) statistics) when FMA contraction matches.
 CXXFLAGS="-std=c++17 -O3 -ffast-math -march=haswell -mtune=haswell -fPIC -Wall -Wno-unused-function -Iinclude -Ihexray_amd/host"
-HOST_SRC="hexray_amd/host/scene_file.cpp hexray_amd/host/image_io.cpp hexray_amd/host/exr_reader.cpp hexray_amd/host/mesh_prep.cpp hexray_amd/host/heightfield_prep.cpp hexray_amd/host/flatten.cpp hexray_amd/host/host_api.cpp"
+HOST_SRC="hexray_amd/host/scene_file.cpp hexray_amd/host/image_io.cpp hexray_amd/host/exr_reader.cpp hexray_amd/host/exr_writer.cpp hexray_amd/host/mesh_prep.cpp hexray_amd/host/heightfield_prep.cpp hexray_amd/host/flatten.cpp hexray_amd/host/host_api.cpp"
 if [ "$what" = all ] || [ "$what" = host ]; then
 	g++ $CXXFLAGS -shared -o hexray_amd/lib/libhexray_host.so $HOST_SRC
 fi

@@ -110,6 +110,9 @@ def host_lib():
         lib.hxh_bucket_list.argtypes = [c_int, c_int, c_int, POINTER(c_int), c_int]
         lib.hxh_save_bmp.argtypes = [c_char_p, c_void_p, c_int, c_int, c_size_t]
         lib.hxh_save_raw.argtypes = [c_char_p, c_void_p, c_int, c_int, c_size_t]
+        lib.hxh_save_exr.argtypes = [c_char_p, c_void_p, c_int, c_int, c_size_t]
+        lib.hxh_float_to_half.restype = ctypes.c_uint
+        lib.hxh_float_to_half.argtypes = [c_float]
         lib.hxh_srgb8.restype = ctypes.c_uint
         lib.hxh_srgb8.argtypes = [c_float]
         lib.hxh_load_image.restype = POINTER(c_float)
@@ -213,6 +216,14 @@ def save_bmp(path: str, frame: np.ndarray):
     f = np.ascontiguousarray(frame, dtype=np.float32)
     h, w, _ = f.shape
     if host_lib().hxh_save_bmp(os.fsencode(path), f.ctypes.data, w, h, w * 12) != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def save_exr(path: str, frame: np.ndarray):
+    """Write a float RGB frame as an OpenEXR file like Bitmap::saveEXR (src/bitmap.cpp:270-288): RGBA HALF, alpha 1."""
+    f = np.ascontiguousarray(frame, dtype=np.float32)
+    h, w, _ = f.shape
+    if host_lib().hxh_save_exr(os.fsencode(path), f.ctypes.data, w, h, w * 12) != 0:
         raise OSError(f"cannot write {path}")
 
 

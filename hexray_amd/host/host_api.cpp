@@ -94,6 +94,13 @@ int hxh_save_bmp(const char* path, const float* rgb, int width, int height, size
 	return hxh::save_bmp(path, rgb, width, height, row_stride_bytes) ? 0 : -1;
 }
 
+int hxh_save_exr(const char* path, const float* rgb, int width, int height, size_t row_stride_bytes)
+{
+	return hxh::save_exr(path, rgb, width, height, row_stride_bytes) ? 0 : -1;
+}
+
+unsigned hxh_float_to_half(float x) { return hxh::float_to_half(x); }
+
 unsigned hxh_srgb8(float x) { return hxh::srgb_table().encode(x); }
 
 float* hxh_load_image(const char* path, int* width, int* height)

@@ -46,6 +46,9 @@ int hxh_bucket_list(int width, int height, int bucket_size, int* rects, int capa
 
 /* Bitmap::saveBMP of a float frame through the sRGB table; 0 on success. */
 int hxh_save_bmp(const char* path, const float* rgb, int width, int height, size_t row_stride_bytes);
+/* Bitmap::saveEXR (src/bitmap.cpp:270-288): RGBA, 16-bit HALF, alpha 1 (written uncompressed; see exr_writer.cpp) */
+int hxh_save_exr(const char* path, const float* rgb, int width, int height, size_t row_stride_bytes);
+unsigned hxh_float_to_half(float x);
 /* Color::toRGB32 per channel. */
 unsigned hxh_srgb8(float x);
 /* Load an image (BMP / EXR) as float RGB; caller frees with hxh_free_pixels. */

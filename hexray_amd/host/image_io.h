@@ -39,5 +39,8 @@ const SrgbTable& srgb_table();
 
 // 24-bit BMP of a float frame (Bitmap::saveBMP, rows bottom-up, padded to 4 bytes)
 bool save_bmp(const std::string& path, const float* rgb, int w, int h, size_t row_stride_bytes);
+// OpenEXR file of a float frame (Bitmap::saveEXR, src/bitmap.cpp:270-288: RGBA, 16-bit HALF, alpha 1); see exr_writer.cpp
+bool save_exr(const std::string& path, const float* rgb, int w, int h, size_t row_stride_bytes);
+uint16_t float_to_half(float f);   // round to nearest even, like Imath's half(float)
 
 }  // namespace hxh

@@ -19,7 +19,7 @@ static void usage()
 {
 	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
 	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc] [--seed S] [--device D]\n"
-	       "              [--frames N] [--out frame.bmp|frame.raw] [--counters] [--accel reference|sah]\n"
+	       "              [--frames N] [--out frame.bmp|frame.exr|frame.raw] [--counters] [--accel reference|sah]\n"
 	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n"
 	       "              [--interactive FRAMES] [--fovea RADIUS]\n");
 }
@@ -158,8 +158,9 @@ int main(int argc, char** argv)
 			       (unsigned long long)k.tri_tests);
 	}
 	if (!out.empty()) {
-		bool raw = out.size() > 4 && out.substr(out.size() - 4) == ".raw";
-		int w = raw ? hxh_save_raw(out.c_str(), vfb.data(), W, H, (size_t)W * 12) : hxh_save_bmp(out.c_str(), vfb.data(), W, H, (size_t)W * 12);
+		bool raw = out.size() > 4 && out.substr(out.size() - 4) == ".raw", exr = out.size() > 4 && out.substr(out.size() - 4) == ".exr";
+		int w = raw ? hxh_save_raw(out.c_str(), vfb.data(), W, H, (size_t)W * 12) : exr ? hxh_save_exr(out.c_str(), vfb.data(), W, H, (size_t)W * 12)
+		                                                                                 : hxh_save_bmp(out.c_str(), vfb.data(), W, H, (size_t)W * 12);
 		if (w) { printf("cannot write %s\n", out.c_str()); return 1; }
 	}
 	if (ds) hxr_scene_destroy(ds);

@@ -215,3 +215,24 @@ def test_exr_piz_decoder_yields_consistent_cube_maps():
     hs = hx.HostScene(scene_path("simple.hexray"))
     assert not any("could not load maps" in w for w in hs.warnings)
     assert desc_of(hs).environment.loaded == 1
+
+
+def test_exr_writer_round_trip(tmp_path):
+    """Bitmap::saveEXR's replacement (RGBA HALF, alpha 1, written uncompressed): what it writes, the EXR reader reads back, and the
+    texels are the float frame rounded to 16-bit HALF exactly as numpy's float16 conversion (round to nearest even) does."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    frame = (rng.random((37, 53, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
+    frame[0, 0] = (0.0, 1.0, 65504.0)            # zero, one, the largest HALF
+    frame[0, 1] = (1e-7, 6.1e-5, 70000.0)        # subnormal HALF range, overflow to inf
+    frame[0, 2] = (-0.25, 0.333333, 2049.0)      # sign, rounding, a tie (2049 -> 2048: even)
+    path = str(tmp_path / "shot.exr")
+    hx.save_exr(path, frame)
+    back = hx.load_image(path)
+    assert back.shape == frame.shape
+    want = frame.astype(np.float16).astype(np.float32)
+    assert np.array_equal(back, want)
+    lib = hx.host_lib()
+    for v in (0.0, 1.0, -2.5, 1e-7, 6.1e-5, 65504.0, 65520.0, 2049.0, 2051.0, 0.1):
+        assert lib.hxh_float_to_half(ctypes.c_float(v)) == int(np.float32(v).astype(np.float16).view(np.uint16)), v
+    assert open(path, "rb").read(4) == bytes([0x76, 0x2f, 0x31, 0x01])
