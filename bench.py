@@ -231,7 +231,7 @@ def main():
                 "hbm_measured_frac": round(traffic / (kernel_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "note": "frac prices the ALGORITHMIC bytes (SURVEY.md 8d) against HBM peak and can exceed what HBM moves: the tables live in cache.  "
                         "hbm_measured_frac = PMC traffic / kernel time / peak; `compute` (PMC, profiles/) is the roofline that binds: instruction issue.",
-                "compute": compute_roofline(args.workload),
+                "compute": compute_roofline(args.workload, kernel_ms_mean),
             }
             result["rays_per_sample"] = round(rays / counters["camera_samples"], 3)
             result["Mrays_per_s"] = round(rays / (kernel_ms_mean * 1e-3) / 1e6, 1)
@@ -321,14 +321,22 @@ def other_timings(hx, hs, accel, W, H, stream, torch, np, frames):
     return out
 
 
-def compute_roofline(workload):
+def compute_roofline(workload, kernel_ms):
     """The roofline that binds (secondary): vector-ALU issue.  From the committed PMC summary of the same workload
-    (profiles/pmc_compute.json, written by tools/pmc_summary.py from separate rocprofv3 --pmc passes); null when there is none."""
+    (profiles/pmc_compute.json, written by tools/profile_collect.py from separate rocprofv3 --pmc passes) and THIS run's kernel time;
+    null when there is no summary for the workload."""
     path = os.path.join(ROOT, "profiles", "pmc_compute.json")
     try:
-        return json.load(open(path)).get(workload)
+        c = json.load(open(path)).get(workload)
     except Exception:
         return None
+    if not c:
+        return None
+    out = {k: c[k] for k in ("bound", "valu_busy_frac", "valu_lane_util", "peak_tflops", "profile")}
+    out["fp64_tflops_nominal"] = round(c["fp64_flop_per_launch_nominal"] / (kernel_ms * 1e-3) / 1e12, 3)
+    out["fp64_tflops_useful"] = round(c["fp64_flop_per_launch_useful"] / (kernel_ms * 1e-3) / 1e12, 3)
+    out["frac_of_fp64_peak"] = round(out["fp64_tflops_useful"] / c["peak_tflops"], 4)
+    return out
 
 
 def usable_cpus():

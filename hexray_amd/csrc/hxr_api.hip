@@ -589,13 +589,14 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
 	if (usable) {
 		const int grid = (int)std::min<uint32_t>((n + 255u) / 256u, 1024u);
+		const int sum_grid = (int)std::min<uint32_t>((n + 255u) / 256u, 64u);   // one 64-bit atomic per wave on ONE word: 4096 of them cost 50 us, 256 cost 3
 		// thresholds in multiples of the mean chunk cost: split into one-pixel packets / start first as a whole
 		uint32_t split_x = 16, first_x = 8;
 		if (const char* e = getenv("HXR_SCHED_SPLIT_X")) split_x = (uint32_t)atoi(e);   // developer aids
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
 		uint32_t frame_div = 1;   // "long against the frame": more than 1/frame_div of a wave's even share of the work (1 beat 2 and 4 at every N)
 		if (const char* e = getenv("HXR_SCHED_FRAME_DIV")) frame_div = (uint32_t)atoi(e);
-		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
+		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
 		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
@@ -735,7 +736,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (tile_pixels) {
 		if (cost_aware) {
-			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 1024u);
+			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
 			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
 		}
 		uint32_t heavy_x = 16;   // frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list)

@@ -80,9 +80,14 @@ HXR_DEV double len2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 HXR_DEV d3 unit(d3 a) { return a * (1.0 / len(a)); }                       // Vector::normalize, src/vector.h:79-83
 HXR_DEV d3 unit_lazy(d3 a)                                                 // normalize(), src/vector.h:160-165
 {
-	double l = len(a);
-	if (fabs(l - 1.0) < 1e-6) return a;
-	return a * (1 / l);
+	// `if (fabs(l - 1) < 1e-6) return a;` decided on l^2: (1 - 1e-6)^2 < l^2 < (1 + 1e-6)^2 is the same interval, and the square
+	// root and the division are only paid for when some lane of the wave leaves it (rays through a node with a scaling transform).
+	// Every ray direction and every rotation-only transform lands inside: smallpt's seven nodes never take the slow path.
+	const double l2 = len2(a);
+	const bool keep = l2 > 0.999998000001 && l2 < 1.000002000001;
+	if (!hxr_ballot(!keep)) return a;
+	const double l = sqrt(l2);
+	return keep ? a : a * (1 / l);
 }
 HXR_DEV double dist3(d3 a, d3 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z)); }
 HXR_DEV d3 faceforward(d3 ray, d3 n) { return dot(ray, n) < 0 ? n : -n; }  // src/vector.h:179-182

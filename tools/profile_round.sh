@@ -1,10 +1,14 @@
 #!/bin/bash
-# Round profile: kernel trace + stats of the default bench, PMC passes for HBM traffic; outputs under gpurun_out/<tag>
-tag=${1:-r01_final}
+# Round profile: kernel trace + stats of the default bench, then PMC passes (counters only, separate runs); outputs under gpurun_out/<tag>.
+# Copy what should be judged into profiles/ afterwards (tools/profile_collect.sh <tag>).
+tag=${1:-r02}
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sah-side > $out/bench.json 2> $out/bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sah-side > $out/bench_under_rocprof.json 2> $out/bench.err
 cd $root
-tools/pmc.sh meshes16 gpurun_out/$tag/pmc > $out/pmc.txt 2>&1
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
-cat $out/bench.json; head -4 $out/kernel_stats.csv; cat $out/pmc.txt | tail -32
+rm -rf $out/trace
+tools/pmc.sh meshes16 gpurun_out/$tag/pmc > $out/pmc.txt 2>&1
+HXR_STACK1=1 tools/pmc.sh meshes16 gpurun_out/$tag/pmc_stack1 > $out/pmc_stack1.txt 2>&1
+rm -rf $out/pmc/pass*/ $out/pmc_stack1/pass*/
+cat $out/bench_under_rocprof.json; head -6 $out/kernel_stats.csv; tail -3 $out/pmc.txt; tail -3 $out/pmc_stack1.txt
