@@ -1794,7 +1794,9 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 #endif
 #define HXR_SCHED_WHOLE 0x80000000u   // schedule item flag: the whole chunk that starts at this pixel
 #define HXR_SCHED_PART 0x40000000u    // schedule item flag: bits 22..29 = which HXR_PART_LANES samples, bits 0..21 = part slot
+#ifndef HXR_PART_LANES
 #define HXR_PART_LANES 4
+#endif
 #define HXR_PART_SLOTS 16384          // pixels that can be split by samples in one frame
 #ifndef HXR_SHARDS
 #define HXR_SHARDS 8          // dispenser counters (power of two)
