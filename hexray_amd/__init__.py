@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libhexray_host.so")
 HIP_LIB_PATH = os.environ.get("HXR_HIP_LIB") or os.path.join(_HERE, "lib", "libhexray_hip.so")   # override: A/B of kernel builds
 
-MODE_AUTO, MODE_SINGLE, MODE_ADAPTIVE_AA, MODE_MONTE_CARLO = 0, 1, 2, 3
+MODE_AUTO, MODE_SINGLE, MODE_ADAPTIVE_AA, MODE_MONTE_CARLO, MODE_PREPASS = 0, 1, 2, 3, 4
 LAYOUT_FRAME, LAYOUT_TILES = 0, 1
 DEFAULT_SEED = 5489
 

@@ -113,6 +113,7 @@ struct hxr_scene {
 	uint32_t* d_qctl = nullptr;         // two control blocks (pass 1 / Monte-Carlo, pass 3) of QCTL_WORDS words
 	long long* d_accum = nullptr;       size_t accum_bytes = 0;
 	bool accum_dirty = false;           // a frame stopped between the continuation pass and the resolve
+	bool no_defer_this_frame = false;   // the prepass fills blocks, not pixels: its rays are traced in place
 	// hxr_render() with a cancel flag or a progress callback: the frame runs on `main_stream` while the calling thread watches
 	// the caller's flag and the per-tile pixel counts through `aux_stream`
 	hipStream_t main_stream = nullptr, aux_stream = nullptr;
@@ -335,6 +336,7 @@ int resolve(const hxr_scene* s, const hxr_frame_params* fp, Plan& p)
 	}
 	if (p.mode == HXR_MODE_MONTE_CARLO) { if (p.spp <= 0) p.spp = rpp > 0 ? rpp : 1; }
 	else if (p.mode == HXR_MODE_SINGLE || p.mode == HXR_MODE_ADAPTIVE_AA) p.spp = 1;
+	else if (p.mode == HXR_MODE_PREPASS) { if (p.spp <= 0) { set_err("HXR_MODE_PREPASS needs spp = prepassSamples > 0"); return HXR_E_INVALID; } }
 	else { set_err("unknown render mode %d", p.mode); return HXR_E_INVALID; }
 	if (p.spp > 65536) { set_err("spp too large"); return HXR_E_INVALID; }
 	p.tile = fp->tile_size > 0 ? fp->tile_size : 64;
@@ -354,6 +356,7 @@ int resolve(const hxr_scene* s, const hxr_frame_params* fp, Plan& p)
 	p.vip_x = fp->vip_x;
 	p.vip_y = fp->vip_y;
 	if (p.fovea < 0 || p.fovea > 1000) { set_err("foveated_radius outside 0..1000"); return HXR_E_INVALID; }   // GlobalSettings::fillProperties, src/scene.cpp:764-778
+	if (p.mode == HXR_MODE_PREPASS && (p.count > 1 || p.layout != HXR_LAYOUT_FRAME)) { set_err("the prepass is an unsharded FRAME-layout frame"); return HXR_E_INVALID; }
 	if (p.fovea > 0 && p.count > 1) { set_err("foveated frames are not sharded (an interactive, single-GPU mode)"); return HXR_E_UNSUPPORTED; }
 	return 0;
 }
@@ -411,7 +414,7 @@ Variant pick_variant(const hxr_scene* s)
 uint64_t defer_capacity(const hxr_scene* s, uint32_t num_chunks, int spp)   // records per sub-queue, 0 = this launch traces in place
 {
 	const Variant v = pick_variant(s);
-	if (!s->defer_allowed || (v != V_MESH && v != V_MESH_REFRACT) || s->fanout0 <= 0 || s->settings.max_trace_depth > 254 || spp > 65535 || num_chunks == 0) return 0;
+	if (!s->defer_allowed || s->no_defer_this_frame || (v != V_MESH && v != V_MESH_REFRACT) || s->fanout0 <= 0 || s->settings.max_trace_depth > 254 || spp > 65535 || num_chunks == 0) return 0;
 	const uint64_t per_shard = ((uint64_t)num_chunks + HXR_SHARDS * HXR_BATCH - 1) / (HXR_SHARDS * HXR_BATCH) * HXR_BATCH;   // as in the kernel
 	const uint64_t rounds = ((uint64_t)spp + 63) / 64;
 	const uint64_t capacity = per_shard * 64 * rounds * (uint64_t)s->fanout0;
@@ -649,6 +652,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	s->aa_cost_aware = false;
 	HxrLaunch L;
 	fill_launch(s, p, L);
+	s->no_defer_this_frame = p.mode == HXR_MODE_PREPASS;
 	L.counters = want_counter_buffer ? s->d_counters : nullptr;
 	const uint32_t tile_pixels = (uint32_t)p.ntiles * (uint32_t)(p.tile * p.tile);
 
@@ -658,6 +662,18 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		hipLaunchKernelGGL(hxr_autofocus_kernel, dim3(1), dim3(64), 0, st, s->dev, V.nodes, V.meshes, V.heightfields, V.geometries, V.kd, V.kd_box, V.hot, V.hot_ids, p.W,
 		                   p.H, focal);
 		HIP_TRY(hipGetLastError());
+	}
+	if (p.mode == HXR_MODE_PREPASS) {   // coarseRender: one "pixel" per 24x24 block, spp = prepassSamples rays each
+		L.mode = 3;
+		L.spp = p.spp;
+		L.pixels_per_chunk = p.spp <= 64 ? 64 / p.spp : 1;
+		const uint32_t blocks = (uint32_t)((p.W + 23) / 24) * (uint32_t)((p.H + 23) / 24);
+		L.num_chunks = (blocks + (uint32_t)L.pixels_per_chunk - 1) / (uint32_t)L.pixels_per_chunk;
+		L.out = d_out;
+		L.out_stride = stride;
+		L.work_counter = s->d_work;
+		L.tile_done = nullptr;
+		return launch_render(s, p, L, counters, st, TIME_BEGIN | TIME_END, 0, 1.0f / (float)L.spp);
 	}
 	if (p.mode == HXR_MODE_MONTE_CARLO || p.mode == HXR_MODE_SINGLE) {
 		L.mode = p.mode == HXR_MODE_MONTE_CARLO ? 1 : 0;

@@ -1925,6 +1925,12 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			uint32_t e = chunk * (uint32_t)ppc + (uint32_t)slot;
 			if (!single) live = live && e < (uint32_t)*P.aa_count;
 			if (live) { int pix = single ? (int)single_pixel : P.aa_list[e]; x = pix % P.W; y = pix / P.W; }   // a listed item IS the frame pixel
+		} else if (mode_ == 3) { // coarseRender (src/main.cpp:387-414): a "pixel" of this pass is a 24x24 block, (x, y) its top-left corner
+			q = chunk * (uint32_t)ppc + (uint32_t)slot;
+			const uint32_t blocks_x = (uint32_t)(P.W + 23) / 24u, blocks = blocks_x * ((uint32_t)(P.H + 23) / 24u);
+			live = live && q < blocks;
+			x = (int)(q % blocks_x) * 24;
+			y = (int)(q / blocks_x) * 24;
 		} else {
 			q = single ? single_pixel : chunk * (uint32_t)ppc + (uint32_t)slot;
 			uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
@@ -1986,6 +1992,12 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 					hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_PIXEL_JITTER), jx, jy);
 					sx = x + jx;
 					sy = y + jy;
+				} else if (mode_ == 3) {   // coarseRender: x + randDouble() * BLK_SIZE, y + randDouble() * BLK_SIZE (src/main.cpp:396)
+					rc.sample = (uint32_t)s;
+					double jx, jy;
+					hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_PREPASS), jx, jy);
+					sx = x + jx * 24;
+					sy = y + jy * 24;
 				} else if (mode_ == 2) {   // pass 3 taps 1..4 of AA_KERNEL; `x + 0.6f` is float arithmetic (src/main.cpp:255-261,336)
 					const float kx[4] = {0.6f, 0.3f, 0.0f, 0.6f}, ky[4] = {0.0f, 0.3f, 0.6f, 0.6f};
 					rc.sample = (uint32_t)(s + 1);
@@ -2021,7 +2033,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		// Combine the samples of each pixel in sample order (the reference adds them one by one, src/main.cpp:372-377).
 		// The lanes of a pixel are adjacent, so the running sum walks through them with one wave-shift per sample:
 		// after step k the lane of sample k holds ((s0 + s1) + ...) + sk.  No LDS round trip, all lanes in lockstep.
-		const bool in_tile = mode_ != 2 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+		const bool in_tile = mode_ != 2 && mode_ != 3 && q < (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
 		float* dst = nullptr;
 		f3 acc = mkf(0, 0, 0);
 		if (live && (sub == 0 || sub == lanes_per_pixel - 1)) {
@@ -2034,11 +2046,19 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			if (sub == k) acc = left + sum;
 		}
 		if (live && sub == lanes_per_pixel - 1) {
-			if (mode_ == 1) acc = acc * (1.0f / spp);
+			if (mode_ == 1 || mode_ == 3) acc = acc * (1.0f / spp);
 			else if (mode_ == 2) acc = acc * (1.0f / 5);
-			dst[0] = acc.x;
-			dst[1] = acc.y;
-			dst[2] = acc.z;
+			if (mode_ == 3) {   // drawRect(r, sum * mul) (src/main.cpp:399): the block's mean fills the block (a display-only preview: one lane writes it)
+				const int x1 = min(x + 24, P.W), y1 = min(y + 24, P.H);
+				for (int py = y; py < y1; py++) {
+					float* row = (float*)((char*)P.out + (size_t)py * P.out_stride);
+					for (int px = x; px < x1; px++) { row[px * 3 + 0] = acc.x; row[px * 3 + 1] = acc.y; row[px * 3 + 2] = acc.z; }
+				}
+			} else {
+				dst[0] = acc.x;
+				dst[1] = acc.y;
+				dst[2] = acc.z;
+			}
 		}
 		if (P.tile_done && in_tile) {   // progress for hxr_render's callback: the pixels of a packet lie in one tile
 			const unsigned long long wrote = hxr_ballot(live && sub == lanes_per_pixel - 1);

@@ -18,7 +18,7 @@
 static void usage()
 {
 	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
-	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc] [--seed S] [--device D]\n"
+	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc|prepass] [--seed S] [--device D]\n"
 	       "              [--frames N] [--out frame.bmp|frame.exr|frame.raw] [--counters] [--accel reference|sah]\n"
 	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n"
 	       "              [--interactive FRAMES] [--fovea RADIUS]\n");
@@ -50,7 +50,7 @@ int main(int argc, char** argv)
 		else if (a == "--spp") { const char* v = next(); c += std::string("numSamples ") + v + "\n"; fp.spp = atoi(v); }
 		else if (a == "--mode") {
 			std::string m = next();
-			fp.mode = m == "single" ? HXR_MODE_SINGLE : m == "aa" ? HXR_MODE_ADAPTIVE_AA : m == "mc" ? HXR_MODE_MONTE_CARLO : HXR_MODE_AUTO;
+			fp.mode = m == "single" ? HXR_MODE_SINGLE : m == "aa" ? HXR_MODE_ADAPTIVE_AA : m == "mc" ? HXR_MODE_MONTE_CARLO : m == "prepass" ? HXR_MODE_PREPASS : HXR_MODE_AUTO;
 		} else if (a == "--seed") fp.rng_seed = strtoull(next(), nullptr, 10);
 		else if (a == "--device") device = atoi(next());
 		else if (a == "--frames") frames = atoi(next());
@@ -71,7 +71,7 @@ int main(int argc, char** argv)
 	}
 	std::string overlay = "GlobalSettings {\nprepassSamples 0\ninteractive off\n" + g + "}\n";
 	if (!c.empty()) overlay += "Camera {\n" + c + "}\n";
-	if (fp.mode != HXR_MODE_MONTE_CARLO) fp.spp = 0;
+	if (fp.mode != HXR_MODE_MONTE_CARLO && fp.mode != HXR_MODE_PREPASS) fp.spp = 0;
 
 	char err[1024] = "";
 	hxh_scene* hs = hxh_scene_load(scene.c_str(), overlay.c_str(), err, sizeof err);

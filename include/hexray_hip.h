@@ -245,7 +245,10 @@ enum hxr_render_mode {
 	HXR_MODE_AUTO = 0,        /* what render() picks (src/main.cpp:416-426): MC if dof/gi, else 1 spp (+AA if wantAA) */
 	HXR_MODE_SINGLE = 1,      /* pass 1 of renderWithoutMonteCarlo only (src/main.cpp:273-314) */
 	HXR_MODE_ADAPTIVE_AA = 2, /* all three passes of renderWithoutMonteCarlo (src/main.cpp:253-345) */
-	HXR_MODE_MONTE_CARLO = 3  /* renderWithMonteCarlo (src/main.cpp:347-384) with `spp` rays per pixel */
+	HXR_MODE_MONTE_CARLO = 3, /* renderWithMonteCarlo (src/main.cpp:347-384) with `spp` rays per pixel */
+	HXR_MODE_PREPASS = 4      /* coarseRender (src/main.cpp:387-414), the preview render() shows first when displayProgress and
+	                             prepassSamples > 0: every 24x24 block is filled with the mean of `spp` (= prepassSamples) rays through
+	                             random points of the block.  The reference paints it on the window only; here it fills the frame. */
 };
 
 enum hxr_output_layout {

@@ -1167,7 +1167,31 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 #endif
 	unsigned char* flags = NULL;
 
-	if (mode == HXR_MODE_MONTE_CARLO) { /* renderWithMonteCarlo, src/main.cpp:347-384 */
+	if (mode == HXR_MODE_PREPASS) { /* coarseRender, src/main.cpp:387-414 (the reference paints the blocks on the window; here they fill the frame) */
+		if (spp <= 0) return -1;
+		float mul = 1.0f / spp;
+		ctx_t cx;
+		memset(&cx, 0, sizeof cx);
+		cx.sc = sc; cx.W = W; cx.H = H; cx.seed = seed; cx.focal_plane_dist = focal;
+		for (int y = 0; y < H; y += 24)
+			for (int x = 0; x < W; x += 24) {
+				col sum = C(0, 0, 0);
+				cx.pixel = (uint32_t)(y * W + x);
+				for (int i = 0; i < spp; i++) {
+					double jx, jy;
+					cx.sample = (uint32_t)i;
+					hxo_uniform2(hxo_philox(seed, cx.pixel, cx.sample, 0, 5), &jx, &jy);
+					sum = cadd(sum, trace_sample(&cx, x + jx * 24, y + jy * 24));
+				}
+				int x1 = x + 24 < W ? x + 24 : W, y1 = y + 24 < H ? y + 24 : H;
+				for (int py = y; py < y1; py++)
+					for (int qx = x; qx < x1; qx++) {
+						float* o = px(out, row_stride_bytes, qx, py);
+						o[0] = sum.r * mul; o[1] = sum.g * mul; o[2] = sum.b * mul;
+					}
+			}
+		counters_add(&total, &cx.cnt);
+	} else if (mode == HXR_MODE_MONTE_CARLO) { /* renderWithMonteCarlo, src/main.cpp:347-384 */
 		float mul = 1.0f / spp;
 #pragma omp parallel
 		{

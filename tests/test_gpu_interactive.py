@@ -102,3 +102,31 @@ def test_hexray_interactive_loop(gpu):
     r = subprocess.run([exe, scene_path("simple.hexray"), "--interactive", "20", "--fovea", "75"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "20 frames in" in r.stdout and "FPS" in r.stdout and "frame latency" in r.stdout and "Exited cleanly" in r.stdout
+
+
+PREPASS = [
+    ("meshes.hexray", hx.overlay_text(333, 250), 5),          # the default prepassSamples; ragged blocks at the right and bottom edges
+    ("smallpt.hexray", hx.overlay_text(200, 150), 3),         # gi on: traceSingleRay path-traces
+    ("meshes.hexray", hx.overlay_text(120, 96, dof=True, num_samples=4), 70),   # more samples per block than lanes in a wave; lens sampling
+]
+
+
+@pytest.mark.parametrize("scene,ov,samples", PREPASS)
+def test_coarse_prepass_matches_oracle(gpu, scene, ov, samples):
+    """coarseRender (src/main.cpp:387-414): every 24x24 block filled with the mean of `prepassSamples` rays through random points of it."""
+    hs = hx.HostScene(scene_path(scene), ov)
+    ds = hx.DeviceScene(hs)
+    fp = dict(mode=hx.MODE_PREPASS, spp=samples)
+    g = ds.render(hx.frame_params(collect_counters=True, **fp))
+    gc = ds.counters()
+    o, oc = oracle_render(hs, hx.frame_params(**fp))
+    assert np.all(rms(g, o) <= 1e-4), rms(g, o)
+    h, w = g.shape[:2]
+    assert gc["camera_samples"] == oc["camera_samples"] == ((w + 23) // 24) * ((h + 23) // 24) * samples
+    for by in range(0, h, 24):                                  # blocks are flat
+        for bx in range(0, w, 24):
+            blk = g[by:by + 24, bx:bx + 24]
+            assert np.all(blk == blk[0, 0])
+    with pytest.raises(hx.HipError):
+        ds.render(hx.frame_params(mode=hx.MODE_PREPASS))       # spp is mandatory
+    ds.close()
