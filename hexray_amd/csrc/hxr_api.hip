@@ -192,6 +192,10 @@ int validate(const hxr_scene_desc* d)
 				if (op < 0 || op >= d->num_geometries) { set_err("CSG operand outside the geometry table"); return HXR_E_INVALID; }
 				int t = d->geometries[op].type;
 				if (t != HXR_GEOM_PLANE && t != HXR_GEOM_SPHERE && t != HXR_GEOM_CUBE) {
+					// CSG over a kd-tree mesh is undefined in the reference itself: CSGBase::intersect tells the operands apart by
+					// `infoCandidate.geom == left` (src/geometry.cpp:186) and Mesh::intersectKD never sets IntersectionInfo::geom
+					// (src/mesh.cpp:247-263: only the brute-force branch does), so the comparison reads an uninitialised pointer.
+					// Nested CSG is defined there but no shipped scene uses it.  Both are refused rather than guessed at.
 					set_err("CSG (node %lld) over a mesh, heightfield or another CSG is not rendered by this build", (long long)i);
 					return HXR_E_UNSUPPORTED;
 				}
