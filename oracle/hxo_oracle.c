@@ -16,12 +16,15 @@
  *   - the full reference program cannot be built here (it needs SDL2 and OpenEXR headers that the
  *     image lacks, and no stand-ins may be written), so whole-frame parity against the reference
  *     binary is UNPINNED;
- *   - pinned pieces: vector/matrix/transform/colour/sRGB math, BBox::testIntersect / inside /
- *     closestIntersection, the analytic primitives, Node::intersect and the lights are checked
- *     against the reference's own translation units compiled in place (oracle/_ref, golden vectors
- *     in tests/golden/); the kd-tree builder and the whole traversal/shading pipeline are checked
- *     against the reference's recorded kd statistics and per-frame call counts (SURVEY.md 8c(iv),
- *     Appendix C).
+ *   - pinned pieces, against the reference's own translation units compiled in place (oracle/_ref, golden vectors in
+ *     tests/golden/): vector/matrix/transform/colour/sRGB math, BBox::testIntersect / inside / closestIntersection / split, the
+ *     analytic primitives, CSG, Node::intersect, the lights (ref_harness.cpp); CheckerTexture / Fresnel / Bumps, Reflection (mirror
+ *     and glossy) / Refraction / Layered ::computeColor with the secondary rays they ask for, the specular BRDFs' eval / spawnRay,
+ *     unitDiskSample, hemisphereSample (ref_harness_shading.cpp, linked against the reference's shading.cpp and util.cpp);
+ *   - count-pinned only (the reference's recorded kd statistics and per-frame call counts): the kd
+ *     builder, Mesh::intersectTriangle / intersectKD, Lambert / Phong::computeColor and the whole traversal / shading pipeline;
+ *   - unpinned: Heightfield, Bitmap-backed lookups (BitmapTexture, BumpTexture, cubemap), Camera -- their translation units need
+ *     SDL2 / OpenEXR headers.
  *
  * Random numbers: see hxo_rng.h (counter-based replacement of the thread-local mt19937).
  */

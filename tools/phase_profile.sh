@@ -1,14 +1,12 @@
 #!/bin/bash
-# Build the render kernel with in-kernel phase clocks and print where the waves' time goes.
-# usage (repo root): tools/phase_profile.sh build            (anywhere: cross-compiles both phase sets)
+# Build the render kernels with in-kernel phase clocks (same per-unit flags as build.sh, through tools/build_alt.sh) and print where
+# the waves' time goes.
+# usage (repo root): tools/phase_profile.sh build            (anywhere: cross-compiles the three phase sets)
 #                    tools/phase_profile.sh [workload ...]   (GPU box)
 set -e
 lib1=hexray_amd/lib/libhexray_hip_timers1.so; lib2=hexray_amd/lib/libhexray_hip_timers2.so; lib3=hexray_amd/lib/libhexray_hip_timers3.so
 if [ "$1" = build ] || [ ! -f $lib1 ] || [ ! -f $lib2 ] || [ ! -f $lib3 ]; then
-	for set in 1 2 3; do
-		hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DHXR_PHASE_TIMERS -DHXR_PHASE_SET=$set -Iinclude -Ihexray_amd/csrc \
-			-o hexray_amd/lib/libhexray_hip_timers$set.so hexray_amd/csrc/hxr_api.hip hexray_amd/csrc/hxr_kernels_mesh.hip hexray_amd/csrc/hxr_kernels_heightfield.hip
-	done
+	for set in 1 2 3; do tools/build_alt.sh timers$set -DHXR_PHASE_TIMERS -DHXR_PHASE_SET=$set; done
 	[ "$1" = build ] && exit 0
 fi
 mkdir -p gpurun_out
