@@ -956,6 +956,13 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		o.shader = n.shader;
 		o.bump = n.bump;
 		o.needs_uv = (n.bump >= 0 || shader_reads_textures(d, n.shader, 0)) ? 1 : 0;
+		o.identity = 1;
+		for (int r = 0; r < 3; r++)
+			for (int c = 0; c < 3; c++) {
+				const double want = r == c ? 1.0 : 0.0;
+				if (n.T.m[r * 3 + c] != want || n.T.inv_m[r * 3 + c] != want || n.T.tinv_m[r * 3 + c] != want) o.identity = 0;
+			}
+		if (getenv("HXR_NO_IDENTITY_NODES")) o.identity = 0;   // developer aid: A/B
 		memcpy(o.p, g.p, sizeof o.p);
 		// object-space bounds of the geometry, if it has finite ones
 		double lo[3], hi[3];

@@ -75,7 +75,7 @@ struct HxrNodeDev {
 	int32_t shader, bump;
 	int32_t cullable;        // cull_lo / cull_hi are valid
 	int32_t needs_uv;        // the node's bump map or a texture in its shader tree reads IntersectionInfo::u / v
-	int32_t pad_;
+	int32_t identity;        // T.m, T.inv_m and T.tinv_m are exactly the identity (a translate-only node): the products are skipped
 	double p[6];             // analytic parameters of the geometry
 	// World-space sphere that encloses everything a ray must reach to get ANY answer other than "miss" from this
 	// node: it contains the transformed, 1e-6-inflated (BBox::inside slack) bounding box of the geometry, with a

@@ -96,6 +96,9 @@ HXR_DEV d3 mulm(d3 v, const double* m)                                     // v 
 {
 	return d3{v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7], v.x * m[2] + v.y * m[5] + v.z * m[8]};
 }
+// v * I evaluated the way mulm evaluates it: x*1 + y*0 + z*0 = x + 0.0 (only the sign of a zero can change): nodes without rotation or
+// scaling -- smallpt's spheres, every floor plane -- skip the 27 multiplications of Node::intersect's three matrix products, bit for bit
+HXR_DEV d3 mul_identity(d3 v) { return d3{v.x + 0.0, v.y + 0.0, v.z + 0.0}; }
 HXR_DEV double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 HXR_DEV f3 mkf(float x, float y, float z) { return f3{x, y, z}; }
@@ -884,10 +887,17 @@ HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, do
 			return false;
 		}
 	}
-	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
-	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
+	d3 ol, dl;
+	if (N.identity) {   // wave-uniform: the matrices of this node are exactly the identity
+		ol = mul_identity(o - ld3(N.T.offset));
+		dl = unit_lazy(mul_identity(d));
+	} else {
+		ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
+		dl = unit_lazy(mulm(d, N.T.inv_m));
+	}
 	if (!geometry_query<COUNT, F>(S, N, ol, dl, g, st, tl)) return false;
-	d3 ipw = mulm(local_hit_point<F>(S, N, ol, dl, g), N.T.m) + ld3(N.T.offset);
+	const d3 lp = local_hit_point<F>(S, N, ol, dl, g);
+	d3 ipw = (N.identity ? mul_identity(lp) : mulm(lp, N.T.m)) + ld3(N.T.offset);
 	wdist = dist3(o, ipw);
 	return true;
 }
@@ -903,8 +913,14 @@ template <bool COUNT, unsigned F>
 HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit& g, double wdist, Surface& sf, Tally<COUNT>& tl)
 {
 	const HxrNodeDev& N = S.nodes[ni];
-	d3 ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
-	d3 dl = unit_lazy(mulm(d, N.T.inv_m));
+	d3 ol, dl;
+	if (N.identity) {
+		ol = mul_identity(o - ld3(N.T.offset));
+		dl = unit_lazy(mul_identity(d));
+	} else {
+		ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
+		dl = unit_lazy(mulm(d, N.T.inv_m));
+	}
 	d3 ip = local_hit_point<F>(S, N, ol, dl, g);
 	d3 n = mk3(0, 0, 0);
 	sf.dNdx = mk3(0, 0, 0);
@@ -980,8 +996,8 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 		}
 		default: break;
 	}
-	sf.ip = mulm(ip, N.T.m) + ld3(N.T.offset);
-	sf.norm = unit(mulm(n, N.T.tinv_m));
+	sf.ip = (N.identity ? mul_identity(ip) : mulm(ip, N.T.m)) + ld3(N.T.offset);
+	sf.norm = unit(N.identity ? mul_identity(n) : mulm(n, N.T.tinv_m));
 	sf.dist = wdist;
 }
 
