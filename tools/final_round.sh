@@ -1,0 +1,18 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one gpurun call: bench lines of every workload, the rocprof / PMC profile of the headline,
+# the 8-way shard bound, the interactive loop.  usage: tools/final_round.sh <tag>
+tag=${1:-r02}
+out=gpurun_out/$tag; mkdir -p $out
+timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err
+: > $out/bench_all_workloads.jsonl
+for w in meshes16 meshes_aa simple1 heightfield16 smallpt16 smallpt256 cornell16 kdtree16; do
+	timeout -k 10 300 python3 bench.py --workload $w --steps 10 --warmup 2 --no-other-timings >> $out/bench_all_workloads.jsonl 2>> $out/bench.err
+done
+timeout -k 10 300 python3 bench.py --accel sah --no-other-timings > $out/bench_sah.json 2>> $out/bench.err
+tools/profile_round.sh $tag > $out/profile.log 2>&1
+HXR_TILE=8 HXR_ALL_RANKS=1 timeout -k 10 300 python3 tools/shard_time.py meshes16 > $out/shard_times_reference_tree.txt 2>&1
+HXR_ACCEL=sah HXR_TILE=8 HXR_ALL_RANKS=1 timeout -k 10 300 python3 tools/shard_time.py meshes16 > $out/shard_times_sah_tree.txt 2>&1
+timeout -k 10 120 hexray_amd/bin/hexray data/simple.hexray --interactive 300 > $out/interactive_simple.txt 2>&1
+timeout -k 10 120 hexray_amd/bin/hexray data/simple.hexray --interactive 300 --fovea 75 >> $out/interactive_simple.txt 2>&1
+timeout -k 10 120 hexray_amd/bin/hexray data/meshes.hexray --width 1920 --height 1080 --dof on --spp 16 --frames 5 --devices 0,0 >> $out/interactive_simple.txt 2>&1
+tail -2 $out/bench.json | cut -c1-600; tail -8 $out/interactive_simple.txt
