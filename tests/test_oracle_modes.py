@@ -89,3 +89,51 @@ def test_other_shipped_scenes_render(scene):
     hs = hx.HostScene(scene_path(scene), hx.overlay_text(48, 36, num_paths=2, num_samples=2))
     img, cnt = oracle_render(hs, hx.frame_params())
     assert np.isfinite(img).all() and img.max() > 0 and cnt["camera_samples"] >= 48 * 36
+
+
+def test_foveated_frame_structure():
+    """Foveated pass 1 as restated from src/main.cpp:284-311: blocks whose centre is outside the radius are flat (one colour = the
+    mean of five rays), blocks inside are the plain frame's pixels, AA only happens inside the fovea, and a radius that covers the
+    frame changes nothing."""
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(200, 150))
+    plain, c0 = oracle_render(hs, hx.frame_params(mode=hx.MODE_SINGLE))
+    vip, radius = (120, 70), 45
+    fov, c1 = oracle_render(hs, hx.frame_params(mode=hx.MODE_SINGLE, foveated_radius=radius, vip=vip))
+    coarse_blocks = fine_blocks = 0
+    for by in range(0, 150, 8):
+        for bx in range(0, 200, 8):
+            blk, ref = fov[by:by + 8, bx:bx + 8], plain[by:by + 8, bx:bx + 8]
+            if (bx + 4 - vip[0]) ** 2 + (by + 4 - vip[1]) ** 2 > radius ** 2:
+                assert np.all(blk == blk[0, 0])
+                coarse_blocks += 1
+            else:
+                assert np.array_equal(blk, ref)
+                fine_blocks += 1
+    assert coarse_blocks > fine_blocks > 10
+    assert c1["camera_samples"] == 5 * coarse_blocks + sum(
+        min(8, 200 - bx) * min(8, 150 - by) for by in range(0, 150, 8) for bx in range(0, 200, 8)
+        if (bx + 4 - vip[0]) ** 2 + (by + 4 - vip[1]) ** 2 <= radius ** 2)
+    aa, c2 = oracle_render(hs, hx.frame_params(mode=hx.MODE_ADAPTIVE_AA, foveated_radius=radius, vip=vip))
+    ys, xs = np.nonzero(np.any(aa != fov, axis=2))
+    assert len(ys) > 0 and np.all((xs - vip[0]) ** 2 + (ys - vip[1]) ** 2 <= radius ** 2)      # only pixels inside the fovea were re-sampled
+    everything, _ = oracle_render(hs, hx.frame_params(mode=hx.MODE_SINGLE, foveated_radius=1000, vip=(100, 75)))
+    assert np.array_equal(everything, plain)
+    nothing_seen_yet, c3 = oracle_render(hs, hx.frame_params(mode=hx.MODE_SINGLE, foveated_radius=30))   # vip = (-100, -100): all coarse
+    assert c3["camera_samples"] == 5 * 25 * 19
+
+
+def test_prepass_blocks():
+    """coarseRender as restated from src/main.cpp:387-414: 24x24 blocks, each the mean of `spp` rays; more rays, less noise."""
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(120, 100))
+    img, c = oracle_render(hs, hx.frame_params(mode=hx.MODE_PREPASS, spp=5))
+    assert c["camera_samples"] == 5 * 5 * 5                      # 5 x 5 blocks (the last row and column are ragged), 5 rays each
+    for by in range(0, 100, 24):
+        for bx in range(0, 120, 24):
+            blk = img[by:by + 24, bx:bx + 24]
+            assert np.all(blk == blk[0, 0])
+    full, _ = oracle_render(hs, hx.frame_params(mode=hx.MODE_SINGLE))
+    means = np.stack([[full[by:by + 24, bx:bx + 24].mean(axis=(0, 1)) for bx in range(0, 120, 24)] for by in range(0, 100, 24)])
+    e5 = np.abs(img[::24, ::24] - means).mean()
+    many, _ = oracle_render(hs, hx.frame_params(mode=hx.MODE_PREPASS, spp=200))
+    e200 = np.abs(many[::24, ::24] - means).mean()
+    assert e200 < e5                                             # converges towards the block means of the real frame
