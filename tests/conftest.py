@@ -24,6 +24,8 @@ def _ensure_built():
         subprocess.run(["bash", os.path.join(ROOT, "build.sh"), "oracle"], check=True)
     if not os.path.exists(os.path.join(ROOT, "hexray_amd", "lib", "libhexray_hip.so")):
         subprocess.run(["bash", os.path.join(ROOT, "build.sh"), "hip"], check=True)
+    if not os.path.exists(os.path.join(ROOT, "hexray_amd", "bin", "hexray")):
+        subprocess.run(["bash", os.path.join(ROOT, "build.sh"), "cli"], check=True)
 
 
 _ensure_built()
