@@ -97,6 +97,8 @@ def host_lib():
         lib = ctypes.CDLL(HOST_LIB_PATH)
         lib.hxh_scene_load.restype = c_void_p
         lib.hxh_scene_load.argtypes = [c_char_p, c_char_p, c_char_p, c_size_t]
+        lib.hxh_scene_load_ex.restype = c_void_p
+        lib.hxh_scene_load_ex.argtypes = [c_char_p, c_char_p, ctypes.c_uint, c_char_p, c_size_t]
         lib.hxh_scene_desc.restype = c_void_p
         lib.hxh_scene_desc.argtypes = [c_void_p]
         lib.hxh_scene_free.argtypes = [c_void_p]
@@ -130,10 +132,12 @@ class HostScene:
     (reference src/scene.cpp:764-778, src/camera.h:57-72), so overrides are expressed the same way.
     """
 
-    def __init__(self, path: str, overlay: str = ""):
+    def __init__(self, path: str, overlay: str = "", gpu_heightfield_tables: bool = False):
+        """``gpu_heightfield_tables``: leave the heightfield maxima tables to the render module (it builds them on the GPU); such a
+        scene is for the HIP module only -- the CPU oracle needs the host's tables."""
         lib = host_lib()
         err = ctypes.create_string_buffer(1024)
-        self._h = lib.hxh_scene_load(os.fsencode(path), overlay.encode(), err, len(err))
+        self._h = lib.hxh_scene_load_ex(os.fsencode(path), overlay.encode(), 1 if gpu_heightfield_tables else 0, err, len(err))
         if not self._h:
             raise ValueError(f"cannot load scene {path}: {err.value.decode(errors='replace')}")
         self.path = path
@@ -263,6 +267,7 @@ def hip_lib():
         lib.hxr_scene_create_ex.argtypes = [c_void_p, POINTER(SceneOptions)]
         lib.hxr_scene_tree_stats.argtypes = [c_void_p, c_int, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(c_int)]
         lib.hxr_scene_update_camera.argtypes = [c_void_p, c_void_p]
+        lib.hxr_scene_verify_tables.argtypes = [c_void_p, c_void_p, POINTER(ctypes.c_int64)]
         lib.hxr_render.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
         lib.hxr_render_device.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p]
         lib.hxr_output_bytes.restype = c_size_t
@@ -346,6 +351,12 @@ class DeviceScene:
     def update_camera(self):
         cam_addr = ctypes.addressof(SceneDescHeader.from_address(self.host.desc).camera)
         _check(hip_lib().hxr_scene_update_camera(self._s, cam_addr), "hxr_scene_update_camera")
+
+    def verify_tables(self, complete_host_scene: HostScene | None = None) -> int:
+        """Number of GPU-prepared table entries (hot triangle records, heightfield maxima) that differ from the host's."""
+        n = ctypes.c_int64()
+        _check(hip_lib().hxr_scene_verify_tables(self._s, (complete_host_scene or self.host).desc, ctypes.byref(n)), "hxr_scene_verify_tables")
+        return n.value
 
     def frame_size(self, params: FrameParams):
         s = self.host.settings

@@ -245,20 +245,12 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, const hxr_kd_
 		boxes.push_back(HxrKdBox{{0, 0, 0}, {0, 0, 0}});
 	}
 	o.kd_first = (int32_t)kd.size();
-	o.hot_first = (int32_t)hot.size();
-	const size_t hot0 = hot.size();
-	auto push_hot = [&](int ti) {
-		const hxr_triangle& t = tris[ti];
-		HxrTriHot h;
-		for (int c = 0; c < 3; c++) {
-			h.A[c] = verts[(size_t)t.v[0] * 3 + c];
-			h.AB[c] = t.AB[c];
-			h.AC[c] = t.AC[c];
-			h.N[c] = t.ABcrossAC[c];
-		}
-		hot.push_back(h);
-		ids.push_back(ti);
-	};
+	o.hot_first = (int32_t)ids.size();
+	const size_t hot0 = ids.size();
+	(void)tris; (void)verts;
+	// only the ORDER of the hot records is decided here (triangle numbers in leaf order); the 96-byte records themselves are
+	// gathered on the device from the cold tables (hxr_expand_hot_kernel)
+	auto push_hot = [&](int ti) { ids.push_back(ti); };
 	if (!m.has_kd || num_nodes == 0) {
 		for (int64_t i = 0; i < m.num_triangles; i++) push_hot((int)i);
 		return 0;
@@ -282,7 +274,7 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, const hxr_kd_
 		for (int c = 0; c < 3; c++) { rb.lo[c] = it.lo[c]; rb.hi[c] = it.hi[c]; }
 		r.split = n.split;
 		if (n.axis == HXR_KD_LEAF) {
-			r.first = (int32_t)(hot.size() - hot0);
+			r.first = (int32_t)(ids.size() - hot0);
 			r.axis_count = HXR_KD_LEAF | (n.count << 2);
 			for (int i = 0; i < n.count; i++) push_hot(leaf_idx[n.first + i]);
 			continue;
@@ -912,8 +904,21 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (s->arena.upload(meshes.data(), meshes.size(), &V.meshes)) return fail();
 	if (s->arena.upload(all_kd.data(), all_kd.size(), &V.kd)) return fail();
 	if (s->arena.upload(all_boxes.data(), all_boxes.size(), &V.kd_box)) return fail();
-	if (s->arena.upload(all_hot.data(), all_hot.size(), &V.hot)) return fail();
 	if (s->arena.upload(all_ids.data(), all_ids.size(), &V.hot_ids)) return fail();
+	if (!all_ids.empty()) {   // the hot records, gathered on the device mesh by mesh
+		void* p = nullptr;
+		if (s->arena.alloc(all_ids.size() * sizeof(HxrTriHot), &p)) return fail();
+		V.hot = (const HxrTriHot*)p;
+		for (int64_t i = 0; i < d->num_meshes; i++) {
+			const HxrMeshDev& o = meshes[(size_t)i];
+			const int64_t end = i + 1 < d->num_meshes ? meshes[(size_t)i + 1].hot_first : (int64_t)all_ids.size();
+			const int64_t n = end - o.hot_first;
+			if (n <= 0) continue;
+			const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+			hipLaunchKernelGGL(hxr_expand_hot_kernel, dim3(grid), dim3(256), 0, nullptr, o.tris, o.vertices, V.hot_ids + o.hot_first, n, (HxrTriHot*)p + o.hot_first);
+		}
+		if (hipGetLastError() != hipSuccess) { set_err("hxr_expand_hot_kernel failed to launch"); return fail(); }
+	}
 
 	std::vector<HxrHeightfieldDev> hfs((size_t)d->num_heightfields);
 	for (int64_t i = 0; i < d->num_heightfields; i++) {
@@ -924,9 +929,31 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		memcpy(o.bbox_min, h.bbox_min, sizeof o.bbox_min);
 		memcpy(o.bbox_max, h.bbox_max, sizeof o.bbox_max);
 		o.heights = d_f32 + h.first_height;
-		o.max_h = d_f32 + h.first_maxh;
-		o.high_map = d_f32 + h.first_highmap;
 		o.normals = d_f64 + h.first_normal * 3;
+		if (h.W <= 0 || h.H <= 0 || h.first_height < 0 || h.first_height + (int64_t)h.W * h.H > d->f32_pool_size) { set_err("bad heightfield ranges"); return fail(); }
+		if (h.first_maxh >= 0 && h.first_highmap >= 0) {
+			o.max_h = d_f32 + h.first_maxh;
+			o.high_map = d_f32 + h.first_highmap;
+		} else {
+			// the host left the maxima tables to the module (first_maxh / first_highmap = -1): pure maxima of the heights, the same
+			// values the host builds (src/heightfield.cpp:49-81,222-235), level by level on the device
+			const int cells = h.W * h.H;
+			void* pm = nullptr;
+			void* ph = nullptr;
+			if (s->arena.alloc((size_t)cells * sizeof(float), &pm) || s->arena.alloc((size_t)cells * 16 * sizeof(float), &ph)) return fail();
+			if (hipMemsetAsync(ph, 0, (size_t)cells * 16 * sizeof(float), nullptr) != hipSuccess) { set_err("hipMemsetAsync failed"); return fail(); }
+			const int grid = std::min((cells + 255) / 256, 2048);
+			hipLaunchKernelGGL(hxr_hf_maxh_kernel, dim3(grid), dim3(256), 0, nullptr, o.heights, h.W, h.H, (float*)pm);
+			o.max_k = 0;
+			if (h.use_optimization) {
+				o.max_k = (int)std::ceil(std::log((double)h.W) / std::log(2.0));   // Heightfield::buildHighMap's maxK
+				if (o.max_k > 16) { set_err("heightfield wider than 65536 texels"); return fail(); }
+				for (int k = 0; k < o.max_k; k++) hipLaunchKernelGGL(hxr_hf_highmap_kernel, dim3(grid), dim3(256), 0, nullptr, o.heights, h.W, h.H, k, (float*)ph);
+			}
+			if (hipGetLastError() != hipSuccess) { set_err("heightfield table kernels failed to launch"); return fail(); }
+			o.max_h = (const float*)pm;
+			o.high_map = (const float*)ph;
+		}
 	}
 	if (s->arena.upload(hfs.data(), hfs.size(), &V.heightfields)) return fail();
 
@@ -1075,6 +1102,8 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	for (int pass = 0; pass < 2; pass++)
 		for (int k = 0; k < 4; k++)
 			if (hipEventCreate(&s->ev_pass[pass][k]) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
+	// the preparation kernels above ran on the null stream; frames may be rendered on streams that do not wait for it
+	if (hipDeviceSynchronize() != hipSuccess) { set_err("scene preparation kernels failed: %s", hipGetErrorString(hipGetLastError())); return fail(); }
 	return s;
 }
 
@@ -1363,6 +1392,56 @@ int hxr_sah_build(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t
 	if (!nodes || !leaf_indices || max_nodes < (int64_t)t.nodes.size() || max_leaf < (int64_t)t.leaf_indices.size()) { set_err("output arrays too small"); return HXR_E_INVALID; }
 	memcpy(nodes, t.nodes.data(), t.nodes.size() * sizeof(hxr_kd_node));
 	if (!t.leaf_indices.empty()) memcpy(leaf_indices, t.leaf_indices.data(), t.leaf_indices.size() * sizeof(int32_t));
+	return 0;
+}
+
+int hxr_scene_verify_tables(const hxr_scene* s, const hxr_scene_desc* d, int64_t* mismatches)
+{
+	if (!s || !d || !mismatches) { set_err("null argument"); return HXR_E_INVALID; }
+	*mismatches = 0;
+	HIP_TRY(hipSetDevice(s->device));
+	const HxrSceneDev& V = s->host_view;
+	// hot triangle records: re-derive every record on the host from the descriptor, in the order the device holds
+	std::vector<HxrMeshDev> meshes((size_t)d->num_meshes);
+	if (d->num_meshes) HIP_TRY(hipMemcpy(meshes.data(), V.meshes, meshes.size() * sizeof(HxrMeshDev), hipMemcpyDeviceToHost));
+	for (int64_t i = 0; i < d->num_meshes; i++) {
+		const hxr_mesh& m = d->meshes[i];
+		const int64_t first = meshes[(size_t)i].hot_first;
+		// the number of hot records of a mesh = leaf entries of the tree walked (or its triangles, without a tree)
+		int64_t n = m.num_triangles;
+		if ((size_t)i < s->tree_stats.size() && meshes[(size_t)i].has_kd) n = s->tree_stats[(size_t)i].leaf_entries;
+		if (n <= 0) continue;
+		std::vector<HxrTriHot> hot((size_t)n);
+		std::vector<int32_t> ids((size_t)n);
+		HIP_TRY(hipMemcpy(hot.data(), V.hot + first, hot.size() * sizeof(HxrTriHot), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(ids.data(), V.hot_ids + first, ids.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+		const hxr_triangle* tris = d->triangles + m.first_triangle;
+		const double* verts = d->f64_pool + m.first_vertex * 3;
+		for (int64_t k = 0; k < n; k++) {
+			if (ids[(size_t)k] < 0 || ids[(size_t)k] >= m.num_triangles) { ++*mismatches; continue; }
+			const hxr_triangle& t = tris[ids[(size_t)k]];
+			HxrTriHot w;
+			for (int c = 0; c < 3; c++) { w.A[c] = verts[(size_t)t.v[0] * 3 + c]; w.AB[c] = t.AB[c]; w.AC[c] = t.AC[c]; w.N[c] = t.ABcrossAC[c]; }
+			if (memcmp(&w, &hot[(size_t)k], sizeof w) != 0) ++*mismatches;
+		}
+	}
+	// heightfield maxima tables against the descriptor's own (when it carries them)
+	std::vector<HxrHeightfieldDev> hfs((size_t)d->num_heightfields);
+	if (d->num_heightfields) HIP_TRY(hipMemcpy(hfs.data(), V.heightfields, hfs.size() * sizeof(HxrHeightfieldDev), hipMemcpyDeviceToHost));
+	for (int64_t i = 0; i < d->num_heightfields; i++) {
+		const hxr_heightfield& h = d->heightfields[i];
+		if (h.first_maxh < 0 || h.first_highmap < 0) continue;
+		const size_t cells = (size_t)h.W * h.H;
+		std::vector<float> mh(cells), hm(cells * 16);
+		HIP_TRY(hipMemcpy(mh.data(), hfs[(size_t)i].max_h, mh.size() * sizeof(float), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hm.data(), hfs[(size_t)i].high_map, hm.size() * sizeof(float), hipMemcpyDeviceToHost));
+		if (hfs[(size_t)i].max_k != h.max_k) ++*mismatches;
+		for (size_t c = 0; c < cells; c++) {
+			if (mh[c] != d->f32_pool[h.first_maxh + (int64_t)c]) ++*mismatches;
+			for (int k = 0; k < h.max_k; k++)
+				if (hm[c * 16 + k] != d->f32_pool[h.first_highmap + (int64_t)(c * 16 + k)]) ++*mismatches;
+		}
+	}
 	return 0;
 }
 

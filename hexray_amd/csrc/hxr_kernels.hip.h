@@ -2439,6 +2439,66 @@ __global__ void hxr_quantize_kernel(const float* __restrict__ frame, size_t stri
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// scene preparation on the device (the parts that are pure copies / maxima and therefore bit-identical to
+// the host's): leaf-ordered hot triangle records, and the heightfield's maxima tables
+// ------------------------------------------------------------------------------------------------
+// One 96-byte hot record per entry of `ids` (triangle numbers local to the mesh, in leaf order): A, AB, AC, ABxAC -- the operands of
+// Mesh::intersectTriangle's rejection tests (src/mesh.cpp:178-195) -- gathered from the cold records already in HBM.
+__global__ void hxr_expand_hot_kernel(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, const int32_t* __restrict__ ids, int64_t n, HxrTriHot* out)
+{
+	for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const hxr_triangle& t = tris[ids[i]];
+		HxrTriHot h;
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			h.A[c] = verts[(size_t)t.v[0] * 3 + c];
+			h.AB[c] = t.AB[c];
+			h.AC[c] = t.AC[c];
+			h.N[c] = t.ABcrossAC[c];
+		}
+		out[i] = h;
+	}
+}
+
+// Heightfield::maxH (src/heightfield.cpp:222-235): the highest of the four corners of a cell (fewer at the last row / column)
+__global__ void hxr_hf_maxh_kernel(const float* __restrict__ heights, int W, int H, float* max_h)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * H; i += gridDim.x * blockDim.x) {
+		const int x = i % W, y = i / W;
+		float m = heights[i];
+		if (x < W - 1) m = fmaxf(m, heights[i + 1]);
+		if (y < H - 1) {
+			m = fmaxf(m, heights[i + W]);
+			if (x < W - 1) m = fmaxf(m, heights[i + W + 1]);
+		}
+		max_h[i] = m;
+	}
+}
+
+// Heightfield::buildHighMap (src/heightfield.cpp:49-81): level 0 = the highest texel of the clamped 3x3 neighbourhood, level k = the highest
+// of level k - 1 at the four corners (+-2^(k-1), +-2^(k-1)), clamped to the map.  One launch per level (each reads the previous one).
+__global__ void hxr_hf_highmap_kernel(const float* __restrict__ heights, int W, int H, int k, float* high_map)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * H; i += gridDim.x * blockDim.x) {
+		const int x = i % W, y = i / W;
+		float r;
+		if (k == 0) {
+			r = heights[i];
+			for (int dy = -1; dy <= 1; dy++)
+				for (int dx = -1; dx <= 1; dx++) r = fmaxf(r, heights[(size_t)clampi(y + dy, H - 1) * W + clampi(x + dx, W - 1)]);
+		} else {
+			const int off = 1 << (k - 1);
+			const int x0 = clampi(x - off, W - 1), x1 = clampi(x + off, W - 1), y0 = clampi(y - off, H - 1), y1 = clampi(y + off, H - 1);
+			r = high_map[((size_t)y0 * W + x0) * 16 + (k - 1)];
+			r = fmaxf(r, high_map[((size_t)y0 * W + x1) * 16 + (k - 1)]);
+			r = fmaxf(r, high_map[((size_t)y1 * W + x0) * 16 + (k - 1)]);
+			r = fmaxf(r, high_map[((size_t)y1 * W + x1) * 16 + (k - 1)]);
+		}
+		high_map[(size_t)i * 16 + k] = r;
+	}
+}
+
 // displayVFB (src/sdl.cpp:79-90): Color::toRGB32 per pixel -- the three 8-bit sRGB channels shifted to where the display surface
 // wants them (src/color.h:84-90) -- into a 32-bit surface with its own pitch
 __global__ void hxr_quantize_rgb32_kernel(const float* __restrict__ frame, size_t stride, int W, int H, const uint8_t* __restrict__ lut, int rshift, int gshift, int bshift,

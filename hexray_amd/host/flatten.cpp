@@ -249,7 +249,7 @@ struct Loader {
 			double blur = 0;
 			b.get_double("blur", blur, 0, 1000);
 			if (!img.ok()) throw ParseError(b.line_end, "Heightfield: could not load the height bitmap");
-			hd.build(img, blur);
+			hd.build(img, blur, !fs.gpu_heightfield_tables);
 			hxr_heightfield h;
 			memset(&h, 0, sizeof h);
 			h.W = hd.W;
@@ -260,10 +260,15 @@ struct Loader {
 			store3(h.bbox_max, hd.bbox_max);
 			h.first_height = int64_t(fs.f32_pool.size());
 			fs.f32_pool.insert(fs.f32_pool.end(), hd.heights.begin(), hd.heights.end());
-			h.first_maxh = int64_t(fs.f32_pool.size());
-			fs.f32_pool.insert(fs.f32_pool.end(), hd.max_h.begin(), hd.max_h.end());
-			h.first_highmap = int64_t(fs.f32_pool.size());
-			fs.f32_pool.insert(fs.f32_pool.end(), hd.high_map.begin(), hd.high_map.end());
+			if (fs.gpu_heightfield_tables) {
+				h.first_maxh = h.first_highmap = -1;
+				h.max_k = 0;
+			} else {
+				h.first_maxh = int64_t(fs.f32_pool.size());
+				fs.f32_pool.insert(fs.f32_pool.end(), hd.max_h.begin(), hd.max_h.end());
+				h.first_highmap = int64_t(fs.f32_pool.size());
+				fs.f32_pool.insert(fs.f32_pool.end(), hd.high_map.begin(), hd.high_map.end());
+			}
 			h.first_normal = add_vectors(hd.normals) / 3;
 			g.ref = int(fs.heightfields.size());
 			fs.heightfields.push_back(h);
@@ -523,7 +528,7 @@ void FlatScene::refresh_desc()
 #undef HXH_TABLE
 }
 
-std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text)
+std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables)
 {
 	std::ifstream in(scene_path);
 	if (!in) throw std::runtime_error("Cannot open scene file `" + scene_path + "'!");
@@ -533,6 +538,7 @@ std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::
 	if (!overlay_text.empty()) merge_overlay(blocks, parse_scene_text(overlay_text, "<overlay>"));
 
 	auto fs = std::make_unique<FlatScene>();
+	fs->gpu_heightfield_tables = gpu_heightfield_tables;
 	// defaults, src/scene.h:244-269
 	set_color(fs->settings.ambient, 0.15f, 0.15f, 0.15f);
 	set_color(fs->settings.background, 0, 0, 0);

@@ -55,13 +55,15 @@ struct FlatScene {
 	std::vector<double> f64_pool;
 	std::vector<float> f32_pool;
 
+	bool gpu_heightfield_tables = false;   // leave maxH / highMap to the render module (hxr_heightfield::first_maxh = first_highmap = -1)
 	hxr_scene_desc desc;
 	void refresh_desc();     // point desc at the vectors
 	void refresh_camera();   // recompute camera basis from camera_spec (Camera::beginFrame)
 };
 
 // Throws ParseError / std::runtime_error.  `overlay_text` may be empty.
-std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text);
+// `gpu_heightfield_tables`: do not build the heightfield maxima tables on the host (the render module builds them on the GPU).
+std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables = false);
 
 // The reference's zig-zag bucket list (src/sdl.cpp:280-294): rects as x0,y0,x1,y1.
 std::vector<int> bucket_list(int width, int height, int bucket_size);

@@ -6,7 +6,7 @@
 
 namespace hxh {
 
-void HeightfieldData::build(Image& bmp, double blur)
+void HeightfieldData::build(Image& bmp, double blur, bool maxima_tables)
 {
 	W = bmp.w;
 	H = bmp.h;
@@ -46,8 +46,9 @@ void HeightfieldData::build(Image& bmp, double blur)
 	bbox_min = V3(0, lo, 0);
 	bbox_max = V3(W, hi, H);
 
-	max_h.assign(size_t(W) * H, 0.0f);
-	for (int y = 0; y < H; y++)
+	max_h.clear();
+	if (maxima_tables) max_h.assign(size_t(W) * H, 0.0f);
+	for (int y = 0; maxima_tables && y < H; y++)
 		for (int x = 0; x < W; x++) {
 			float m = heights[size_t(y) * W + x];
 			if (x < W - 1) m = std::max(m, heights[size_t(y) * W + x + 1]);
@@ -72,7 +73,7 @@ void HeightfieldData::build(Image& bmp, double blur)
 
 	high_map.clear();
 	max_k = 0;
-	if (!use_optimization) return;
+	if (!use_optimization || !maxima_tables) return;
 	high_map.assign(size_t(W) * H * 16, 0.0f);
 	max_k = int(std::ceil(std::log(W) / std::log(2.0)));
 	auto clampi = [](int v, int hi_) { return std::max(0, std::min(hi_, v)); };

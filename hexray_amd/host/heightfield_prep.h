@@ -16,7 +16,7 @@ struct HeightfieldData {
 	std::vector<float> high_map;   // 16 floats per cell
 	V3 bbox_min, bbox_max;
 
-	void build(Image& bmp, double blur);
+	void build(Image& bmp, double blur, bool maxima_tables = true);   // false: max_h / high_map / max_k are left to the render module (hxr_heightfield::first_maxh = -1)
 };
 
 }  // namespace hxh

@@ -19,6 +19,10 @@ typedef struct hxh_scene hxh_scene;
 /* Parse `scene_path` (+ optional overlay text in .hexray syntax), load its assets, run the
  * beginRender/beginFrame preparation and flatten.  NULL on failure with a message in err. */
 hxh_scene* hxh_scene_load(const char* scene_path, const char* overlay_text, char* err, size_t err_len);
+/* flags: HXH_GPU_HEIGHTFIELD_TABLES = leave Heightfield::maxH / highMap (src/heightfield.cpp:49-81,222-235) to the render module, which
+ * builds them on the GPU (hxr_heightfield::first_maxh = first_highmap = -1).  A descriptor loaded this way is for the HIP module only. */
+enum { HXH_GPU_HEIGHTFIELD_TABLES = 1u };
+hxh_scene* hxh_scene_load_ex(const char* scene_path, const char* overlay_text, unsigned flags, char* err, size_t err_len);
 const hxr_scene_desc* hxh_scene_desc(const hxh_scene* s);
 void hxh_scene_free(hxh_scene* s);
 

@@ -74,7 +74,7 @@ int main(int argc, char** argv)
 	if (fp.mode != HXR_MODE_MONTE_CARLO && fp.mode != HXR_MODE_PREPASS) fp.spp = 0;
 
 	char err[1024] = "";
-	hxh_scene* hs = hxh_scene_load(scene.c_str(), overlay.c_str(), err, sizeof err);
+	hxh_scene* hs = hxh_scene_load_ex(scene.c_str(), overlay.c_str(), HXH_GPU_HEIGHTFIELD_TABLES, err, sizeof err);   // the module builds the maxima tables on the GPU
 	if (!hs) {
 		printf("Could not parse the scene file (%s)!\n%s\n", scene.c_str(), err);
 		return 1;

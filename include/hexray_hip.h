@@ -107,8 +107,8 @@ typedef struct hxr_heightfield {
 	int32_t W, H, max_k, use_optimization;
 	double bbox_min[3], bbox_max[3];
 	int64_t first_height;    /* f32_pool, W*H            heights[y*W+x] */
-	int64_t first_maxh;      /* f32_pool, W*H            maxH[y*W+x]    */
-	int64_t first_highmap;   /* f32_pool, W*H*16         highMap[y*W+x].h[k] */
+	int64_t first_maxh;      /* f32_pool, W*H            maxH[y*W+x];  -1 together with first_highmap = not provided: the module    */
+	int64_t first_highmap;   /* f32_pool, W*H*16         highMap[y*W+x].h[k]   builds both on the GPU from the heights (max_k too) */
 	int64_t first_normal;    /* f64_pool, counted in 3-double VECTORS like hxr_mesh: normals[y*W+x] */
 } hxr_heightfield;
 
@@ -351,6 +351,12 @@ int hxr_sah_build(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int6
 /* Nodes / leaf entries / depth of the tree actually walked for mesh `mesh` (after an HXR_ACCEL_SAH rebuild these
  * differ from the descriptor's).  The reference prints the same statistics at load (src/mesh.cpp:39-47). */
 int hxr_scene_tree_stats(const hxr_scene* scene, int mesh, int64_t* nodes, int64_t* leaf_entries, int* max_depth);
+
+/* Checks the tables the module prepared on the GPU at hxr_scene_create -- the leaf-ordered hot triangle records and, when the
+ * scene was created from a descriptor WITHOUT heightfield maxima tables, those tables -- against the host's: every hot record is
+ * re-derived from `desc`, the maxima tables are compared with the ones `desc` carries (pass the complete descriptor here).
+ * *mismatches receives the number of differing records / values: the preparation is pure copies and maxima, so it must be 0. */
+int hxr_scene_verify_tables(const hxr_scene* scene, const hxr_scene_desc* desc, int64_t* mismatches);
 
 /* Per-frame camera update (Camera::beginFrame, src/camera.cpp:30-63, after move/rotate). */
 int hxr_scene_update_camera(hxr_scene* scene, const hxr_camera* camera);

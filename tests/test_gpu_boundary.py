@@ -116,3 +116,24 @@ def test_hexray_binary_as_a_child_process(gpu, tmp_path):
         if "--progress" in extra:
             assert "tiles reported: 80" in r.stdout
         raw.unlink()
+
+
+def test_scene_tables_prepared_on_the_gpu(gpu):
+    """hxr_scene_create builds the leaf-ordered hot triangle records on the GPU (both trees), and -- for a descriptor loaded without
+    them -- the heightfield's maxH / highMap tables: pure copies and maxima, so every value must equal the host's (0 mismatches), and the
+    frames must not change."""
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(160, 120))
+    for accel in (hx.ACCEL_REFERENCE, hx.ACCEL_SAH):
+        ds = hx.DeviceScene(hs, accel=accel)
+        assert ds.verify_tables() == 0
+        ds.close()
+    full = hx.HostScene(scene_path("heightfield.hexray"), hx.overlay_text(240, 135))
+    lean = hx.HostScene(scene_path("heightfield.hexray"), hx.overlay_text(240, 135), gpu_heightfield_tables=True)
+    from desc_types import desc_of
+    assert desc_of(lean).heightfields[0].first_maxh == -1 and desc_of(full).heightfields[0].first_maxh >= 0
+    assert desc_of(lean).f32_pool_size < desc_of(full).f32_pool_size - 512 * 512 * 16
+    a, b = hx.DeviceScene(full), hx.DeviceScene(lean)
+    assert b.verify_tables(full) == 0 and a.verify_tables() == 0
+    p = hx.frame_params(mode=hx.MODE_ADAPTIVE_AA)
+    assert np.array_equal(a.render(p), b.render(p))
+    a.close(); b.close()

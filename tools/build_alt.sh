@@ -6,11 +6,12 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p build/alt_$tag
 HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -Ihexray_amd/csrc $*"
-hipcc $HIPFLAGS -O2 -mllvm -amdgpu-sched-strategy=max-ilp -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
+MESH_FLAGS=${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp}   # flags of the kd-walking translation units (override for compiler-flag A/Bs)
+hipcc $HIPFLAGS $MESH_FLAGS -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
 p1=$!
 hipcc $HIPFLAGS -O2 -c -o build/alt_$tag/hf.o hexray_amd/csrc/hxr_kernels_heightfield.hip &
 p2=$!
-hipcc $HIPFLAGS -O2 -mllvm -amdgpu-sched-strategy=max-ilp -c -o build/alt_$tag/mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
+hipcc $HIPFLAGS $MESH_FLAGS -c -o build/alt_$tag/mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
 p3=$!
 hipcc $HIPFLAGS -O3 -c -o build/alt_$tag/api.o hexray_amd/csrc/hxr_api.hip
 wait $p1; wait $p2; wait $p3
