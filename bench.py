@@ -35,6 +35,8 @@ WORKLOADS = {
                  "data/meshes.hexray 1920x1080 x 16 spp (Camera dof on, numSamples 16; renderWithMonteCarlo)"),
     "meshes_aa": ("meshes.hexray", dict(width=1920, height=1080),
                   "data/meshes.hexray 1920x1080 adaptive 5-tap AA (as shipped; renderWithoutMonteCarlo)"),
+    "meshes1": ("meshes.hexray", dict(width=1920, height=1080, want_aa=False),
+                "data/meshes.hexray 1920x1080 x 1 spp (pass 1 of renderWithoutMonteCarlo alone)"),
     "simple1": ("simple.hexray", dict(width=1920, height=1080, want_aa=False),
                 "data/simple.hexray 1920x1080 x 1 spp"),
     "heightfield16": ("heightfield.hexray", dict(width=1920, height=1080, dof=True, num_samples=16),

@@ -730,7 +730,13 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	const uint32_t list_capacity = tile_pixels + 64u;
 	const bool cost_aware = s->adaptive && L.num_chunks >= 1024 && !getenv("HXR_AA_NO_COST") && !defer_capacity(s, L.num_chunks, L.spp) && p.fovea == 0;
 	s->aa_cost_aware = cost_aware;
-	if (cost_aware) {
+	// Pass 1 itself is scheduled from the previous frame's pass-1 costs like a 1-spp frame (chunks that were expensive go first, one pixel
+	// per packet): unscheduled, ONE 64-pixel packet in the crease of the heart holds the pass for 3.8 ms of a 1.3 ms pass.
+	const bool schedule_pass1 = cost_aware && L.num_chunks >= 4096 && !getenv("HXR_AA_NO_PASS1_SCHEDULE");
+	if (schedule_pass1) {
+		rc = prepare_schedule(s, p, L, tile_pixels, st);   // also clears the cost array this pass writes and pass 3 reads
+		if (rc) return rc;
+	} else if (cost_aware) {
 		rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)L.num_chunks * sizeof(uint32_t));
 		if (!rc) rc = ensure((void**)&s->d_sched_flags, &s->sched_flags_cap, (size_t)L.num_chunks);
 		if (rc) return rc;
@@ -748,6 +754,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (tile_pixels) {
 		if (cost_aware) {
+			if (schedule_pass1) HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));   // pass 1's list counters are done with; the words now serve pass 3
 			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
 			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
 		}
