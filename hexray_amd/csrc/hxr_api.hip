@@ -114,6 +114,9 @@ struct hxr_scene {
 	long long* d_accum = nullptr;       size_t accum_bytes = 0;
 	bool accum_dirty = false;           // a frame stopped between the continuation pass and the resolve
 	bool no_defer_this_frame = false;   // the prepass fills blocks, not pixels: its rays are traced in place
+	struct HotSphere { double c[3], r; };
+	std::vector<HotSphere> hot_spheres; // world bounding spheres of the bounded nodes whose shaders spawn secondary rays (first-frame schedule)
+	bool hot_everywhere = false;        // an unbounded node (a plane) spawns secondary rays: no region stands out
 	// hxr_render() with a cancel flag or a progress callback: the frame runs on `main_stream` while the calling thread watches
 	// the caller's flag and the per-tile pixel counts through `aux_stream`
 	hipStream_t main_stream = nullptr, aux_stream = nullptr;
@@ -601,8 +604,56 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
 		HIP_TRY(hipGetLastError());
 	} else {
-		HIP_TRY(hipMemsetAsync(s->d_sched_cost, 0, (size_t)n * sizeof(uint32_t), st));
-		HIP_TRY(hipMemsetAsync(s->d_sched_flags, 0, (size_t)n, st));
+		// No cost map yet.  Where can long chains of secondary rays be?  Only on the screen footprint of nodes whose shaders spawn them:
+		// their chunks go first (whole), so that an 8 ms packet in the crease of a mirror starts at the beginning of the frame instead of
+		// wherever frame order reaches it (first frame of the headline: 10.5 -> 9.x ms).
+		HxrRects R;
+		memset(&R, 0, sizeof R);
+		if (!s->hot_everywhere && !getenv("HXR_SCHED_NO_RECTS")) {
+			const hxr_camera& c = s->camera;
+			double a[3], b[3];
+			for (int k = 0; k < 3; k++) { a[k] = c.top_right[k] - c.top_left[k]; b[k] = c.bottom_left[k] - c.top_left[k]; }
+			for (const auto& hsph : s->hot_spheres) {
+				if (R.n >= 8) { R.n = 0; break; }   // too many to be worth telling apart
+				double lo[2] = {1e30, 1e30}, hi[2] = {-1e30, -1e30};
+				bool behind = false;
+				for (int corner = 0; corner < 8 && !behind; corner++) {
+					double d3[3], rhs[3];
+					for (int k = 0; k < 3; k++) {
+						d3[k] = hsph.c[k] + ((corner >> k) & 1 ? hsph.r : -hsph.r) - c.pos[k];   // P - pos
+						rhs[k] = c.pos[k] - c.top_left[k];
+					}
+					// u a + v b - w (P - pos) = pos - top_left  (Cramer); w > 0: the corner is in front of the camera
+					auto det = [](const double* x, const double* y, const double* z) {
+						return x[0] * (y[1] * z[2] - y[2] * z[1]) - y[0] * (x[1] * z[2] - x[2] * z[1]) + z[0] * (x[1] * y[2] - x[2] * y[1]);
+					};
+					const double nd[3] = {-d3[0], -d3[1], -d3[2]};
+					const double D = det(a, b, nd);
+					if (std::fabs(D) < 1e-300) { behind = true; break; }
+					const double u = det(rhs, b, nd) / D, v = det(a, rhs, nd) / D, w = det(a, b, rhs) / D;
+					if (!(w > 1e-9)) { behind = true; break; }
+					lo[0] = std::min(lo[0], u); hi[0] = std::max(hi[0], u);
+					lo[1] = std::min(lo[1], v); hi[1] = std::max(hi[1], v);
+				}
+				if (behind) { R.n = 0; break; }
+				const double margin = 0.03;   // depth-of-field blur, bump-mapped silhouettes
+				const int x0 = (int)std::floor((lo[0] - margin) * p.W), x1 = (int)std::ceil((hi[0] + margin) * p.W);
+				const int y0 = (int)std::floor((lo[1] - margin) * p.H), y1 = (int)std::ceil((hi[1] + margin) * p.H);
+				if (x1 <= 0 || y1 <= 0 || x0 >= p.W || y0 >= p.H) continue;   // off screen
+				if ((double)(std::min(x1, p.W) - std::max(x0, 0)) * (std::min(y1, p.H) - std::max(y0, 0)) > 0.4 * p.W * p.H) { R.n = 0; break; }   // most of the frame: nothing to put first
+				R.r[R.n][0] = x0; R.r[R.n][1] = y0; R.r[R.n][2] = x1; R.r[R.n][3] = y1;
+				R.n++;
+			}
+		}
+		if (R.n > 0) {
+			const int grid = (int)std::min<uint32_t>((n + 255u) / 256u, 1024u);
+			hipLaunchKernelGGL(hxr_sched_rects_kernel, dim3(grid), dim3(256), 0, st, L, R, n, (uint32_t)L.pixels_per_chunk, num_pixels, s->d_sched_cost, s->d_sched_flags,
+			                   s->d_sched_items, capacity, (uint32_t*)s->d_sched_ctl + 2);
+			HIP_TRY(hipGetLastError());
+		} else {
+			HIP_TRY(hipMemsetAsync(s->d_sched_cost, 0, (size_t)n * sizeof(uint32_t), st));
+			HIP_TRY(hipMemsetAsync(s->d_sched_flags, 0, (size_t)n, st));
+		}
 	}
 	L.sched_cost = s->d_sched_cost;
 	L.sched_flags = s->d_sched_flags;
@@ -1037,6 +1088,15 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 			o.cull_hi[0] = r * r;
 			o.cull_hi[1] = o.cull_hi[2] = 0;
 			o.cullable = (ok && std::isfinite(o.cull_hi[0])) ? 1 : 0;
+		}
+		{   // does a hit of this node spawn secondary rays?  (first-frame schedule, prepare_schedule)
+			int rays = 0, pending = 1;
+			bool glossy = false, cyclic = false;
+			shader_fanout(d, n.shader, 0, rays, pending, glossy, cyclic);
+			if (rays > 0) {
+				if (o.cullable) s->hot_spheres.push_back({{o.cull_lo[0], o.cull_lo[1], o.cull_lo[2]}, std::sqrt(o.cull_hi[0])});
+				else s->hot_everywhere = true;
+			}
 		}
 	}
 	if (s->arena.upload(nodes.data(), nodes.size(), &V.nodes)) return fail();

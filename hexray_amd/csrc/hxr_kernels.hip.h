@@ -2314,6 +2314,25 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_resolve_kernel(HxrLaunch P, flo
 	}
 }
 
+// Adaptive schedule without history (the first frame of a scene, a new frame size ...): chunks inside the screen rectangles of nodes that
+// spawn secondary rays -- where long reflection chains can only be -- are listed WHOLE at the back of `items`, i.e. started first, the way
+// the cost map would list expensive-but-coherent chunks.  Nothing is split: that needs measured costs.  The image does not depend on it.
+struct HxrRects { int32_t n; int32_t r[8][4]; };   // x0, y0, x1, y1 (exclusive), frame pixels
+__global__ void hxr_sched_rects_kernel(HxrLaunch P, HxrRects R, uint32_t n, uint32_t ppc, uint32_t num_pixels, uint32_t* cost, uint8_t* flags, uint32_t* items, uint32_t capacity,
+                                       uint32_t* counts)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		cost[i] = 0;
+		const uint32_t first = i * ppc;
+		bool inside = false;
+		int x, y;
+		if (first < num_pixels && shard_pixel(P, first, x, y))
+			for (int k = 0; k < R.n; k++) inside = inside || (x >= R.r[k][0] && x < R.r[k][2] && y >= R.r[k][1] && y < R.r[k][3]);
+		if (inside) items[capacity - 1u - atomicAdd(counts + 1, 1u)] = first | HXR_SCHED_WHOLE;
+		flags[i] = inside ? 1 : 0;
+	}
+}
+
 // Autofocus probe of renderWithMonteCarlo (src/main.cpp:350-362): the distance to the closest node along the
 // ray through the frame centre becomes the focal plane distance.  One wavefront, every lane the same ray.
 __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
