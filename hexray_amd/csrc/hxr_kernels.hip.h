@@ -1810,6 +1810,10 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 #endif
 #define HXR_SCHED_WHOLE 0x80000000u   // schedule item flag: the whole chunk that starts at this pixel
 #define HXR_SCHED_PART 0x40000000u    // schedule item flag: bits 22..29 = which HXR_PART_LANES samples, bits 0..21 = part slot
+#define HXR_SCHED_QUARTER 0x20000000u // schedule item flag (not a PART): the HXR_QUARTER_LANES pixels that start at this pixel (1-spp packets only)
+#ifndef HXR_QUARTER_LANES
+#define HXR_QUARTER_LANES 16
+#endif
 #ifndef HXR_PART_LANES
 #define HXR_PART_LANES 4
 #endif
@@ -1928,12 +1932,14 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		const bool part = listed && (single_pixel & HXR_SCHED_PART);        // HXR_PART_LANES samples of one pixel
 		const uint32_t part_slot = single_pixel & 0x3fffffu, part_group = (single_pixel >> 22) & 0xffu;
 		if (part) single_pixel = P.sched_part_pixels[part_slot];
-		const bool single = listed && !(single_pixel & HXR_SCHED_WHOLE);   // one pixel only; a listed WHOLE chunk is an ordinary packet
-		single_pixel &= ~HXR_SCHED_WHOLE;
+		const bool quarter = listed && !part && (single_pixel & HXR_SCHED_QUARTER);   // a run of HXR_QUARTER_LANES pixels of a 1-spp chunk
+		const bool single = listed && !quarter && !(single_pixel & HXR_SCHED_WHOLE);   // one pixel only; a listed WHOLE chunk is an ordinary packet
+		single_pixel &= ~(HXR_SCHED_WHOLE | (part ? 0u : HXR_SCHED_QUARTER));
 		const uint32_t chunk = listed ? single_pixel / (uint32_t)P.pixels_per_chunk : batch_pos++;
 		const int slot = lane / lanes_per_pixel;               // which pixel of the chunk this lane works for
 		const int sub = lane - slot * lanes_per_pixel;         // which sample of that pixel (first round)
-		bool live = single ? slot == 0 : slot < ppc;           // lanes that belong to a pixel of this packet
+		const int quarter_first = quarter ? (int)(single_pixel - chunk * (uint32_t)P.pixels_per_chunk) : 0;
+		bool live = single ? slot == 0 : quarter ? (slot >= quarter_first && slot < quarter_first + HXR_QUARTER_LANES && slot < ppc) : slot < ppc;   // lanes that belong to a pixel of this packet
 		// which pixel
 		int x = 0, y = 0;
 		uint32_t q = 0;
@@ -2084,7 +2090,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			}
 		}
 		if (scheduled && !part && lane == 0) {   // what this chunk cost (a single pixel stands for its ppc-pixel chunk)
-			unsigned long long dt = (__builtin_readcyclecounter() - packet_t0) * (single ? (unsigned long long)ppc : 1ull);
+			unsigned long long dt = (__builtin_readcyclecounter() - packet_t0) * (single ? (unsigned long long)ppc : quarter ? (unsigned long long)(ppc / HXR_QUARTER_LANES) : 1ull);
 			atomicMax(P.sched_cost + chunk, (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
 		}
 		tl.template lap<PH_REDUCE>();
@@ -2316,11 +2322,14 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_resolve_kernel(HxrLaunch P, flo
 
 // Adaptive schedule without history (the first frame of a scene, a new frame size ...): chunks inside the screen rectangles of nodes that
 // spawn secondary rays -- where long reflection chains can only be -- are listed WHOLE at the back of `items`, i.e. started first, the way
-// the cost map would list expensive-but-coherent chunks.  Nothing is split: that needs measured costs.  The image does not depend on it.
+// the cost map would list expensive-but-coherent chunks.  Monte-Carlo chunks are not split (that needs measured costs); the 64-pixel chunks
+// of 1-spp passes are handed out in four runs of sixteen pixels, because a wave that holds 64 unrelated reflection chains IS the frame
+// time (4 ms of a 1.3 ms pass).  The image does not depend on any of it.
 struct HxrRects { int32_t n; int32_t r[8][4]; };   // x0, y0, x1, y1 (exclusive), frame pixels
 __global__ void hxr_sched_rects_kernel(HxrLaunch P, HxrRects R, uint32_t n, uint32_t ppc, uint32_t num_pixels, uint32_t* cost, uint8_t* flags, uint32_t* items, uint32_t capacity,
                                        uint32_t* counts)
 {
+	const bool quarters = P.spp == 1 && ppc == 64 && P.mode == 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		cost[i] = 0;
 		const uint32_t first = i * ppc;
@@ -2328,7 +2337,12 @@ __global__ void hxr_sched_rects_kernel(HxrLaunch P, HxrRects R, uint32_t n, uint
 		int x, y;
 		if (first < num_pixels && shard_pixel(P, first, x, y))
 			for (int k = 0; k < R.n; k++) inside = inside || (x >= R.r[k][0] && x < R.r[k][2] && y >= R.r[k][1] && y < R.r[k][3]);
-		if (inside) items[capacity - 1u - atomicAdd(counts + 1, 1u)] = first | HXR_SCHED_WHOLE;
+		if (inside) {
+			if (quarters) {   // 1-spp packets (64 pixels): sixteen pixels per packet, so that 64 unrelated chains do not share one wave
+				const uint32_t at = atomicAdd(counts + 1, ppc / HXR_QUARTER_LANES);
+				for (uint32_t k = 0; k < ppc / HXR_QUARTER_LANES; k++) items[capacity - 1u - (at + k)] = (first + k * HXR_QUARTER_LANES) | HXR_SCHED_QUARTER;
+			} else items[capacity - 1u - atomicAdd(counts + 1, 1u)] = first | HXR_SCHED_WHOLE;
+		}
 		flags[i] = inside ? 1 : 0;
 	}
 }
