@@ -600,3 +600,37 @@ def test_smallpt_256_paths_accounting_and_determinism(gpu):
     g, gc, o, oc = both("smallpt.hexray", hx.overlay_text(160, 90, num_paths=256), dict())
     assert np.all(rms(g, o) <= RMS_BAR) and gc["camera_samples"] == oc["camera_samples"] == 160 * 90 * 256
     assert abs(g.mean() - o.mean()) <= 0.005 * o.mean()               # energy: mean luminance within 0.5 %
+
+
+def test_scheduled_aa_pass_one_whole_and_sharded(gpu):
+    """Adaptive AA at a size where pass 1 itself is scheduled (first frame: hot rectangles in runs of sixteen pixels; later frames: the
+    previous frame's pass-1 costs), whole and as two shards with halos: every frame equals the unscheduled one bit for bit, and the
+    flagged-pixel count does not move."""
+    import torch
+    from hexray_amd.distributed import padded_tiles_per_rank
+    W, H, world, tile = 1920, 1080, 2, 16
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(W, H))
+    fp = dict(mode=hx.MODE_ADAPTIVE_AA)
+    plain_scene = hx.DeviceScene(hs, adaptive_schedule=False)
+    plain = plain_scene.render(hx.frame_params(collect_counters=True, **fp))
+    flagged = plain_scene.counters()["aa_pixels"]
+    ds = hx.DeviceScene(hs)
+    for frame_no in range(3):
+        f = ds.render(hx.frame_params(collect_counters=(frame_no == 2), **fp))
+        assert np.array_equal(f, plain), frame_no
+    assert ds.counters()["aa_pixels"] == flagged
+    slots = padded_tiles_per_rank(W, H, tile, world)
+    st = torch.cuda.current_stream().cuda_stream
+    ranks = [hx.DeviceScene(hs) for _ in range(world)]
+    for frame_no in range(2):
+        parts = []
+        for rank in range(world):
+            p = hx.frame_params(tile_size=tile, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES, **fp)
+            buf = torch.zeros(slots * tile * tile * 3, dtype=torch.float32, device="cuda")
+            ranks[rank].render_device(p, buf.data_ptr(), 0, st)
+            parts.append(buf)
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        p0 = hx.frame_params(tile_size=tile, shard_rank=0, shard_count=world, layout=hx.LAYOUT_TILES, **fp)
+        ranks[0].assemble_frame(p0, torch.cat(parts).data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, st)
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), plain), frame_no
