@@ -1059,6 +1059,19 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		else bounded = false;   // planes (possibly unlimited) and CSG are always scanned
 		for (int c = 0; c < 3 && bounded; c++) bounded = std::isfinite(lo[c]) && std::isfinite(hi[c]) && lo[c] <= hi[c];
 		o.cullable = 0;
+		if (g.type == HXR_GEOM_PLANE && !getenv("HXR_NO_PLANE_SIDE_TEST")) {
+			// world-space side test of a plane node (node_query): s(p) = (p - offset) . c - py with c = the y-column of inv_m
+			const double c[3] = {n.T.inv_m[1], n.T.inv_m[4], n.T.inv_m[7]};
+			const double k = n.T.offset[0] * c[0] + n.T.offset[1] * c[1] + n.T.offset[2] * c[2] + g.p[0];
+			const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+			if (std::isfinite(k) && std::isfinite(cn) && cn > 0) {
+				memcpy(o.cull_lo, c, sizeof c);
+				o.cull_hi[0] = k;
+				o.cull_hi[1] = cn;
+				o.cull_hi[2] = 0;
+				o.cullable = 2;
+			}
+		}
 		if (bounded) {
 			double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300}, scale = 0;
 			for (int c = 0; c < 3; c++) {   // the reference's own slacks: BBox::inside +-1e-6 (src/bbox.h:80-85), Cube inBounds +-1e-6 (src/geometry.cpp:87-95)
@@ -1094,7 +1107,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 			bool glossy = false, cyclic = false;
 			shader_fanout(d, n.shader, 0, rays, pending, glossy, cyclic);
 			if (rays > 0) {
-				if (o.cullable) s->hot_spheres.push_back({{o.cull_lo[0], o.cull_lo[1], o.cull_lo[2]}, std::sqrt(o.cull_hi[0])});
+				if (o.cullable == 1) s->hot_spheres.push_back({{o.cull_lo[0], o.cull_lo[1], o.cull_lo[2]}, std::sqrt(o.cull_hi[0])});
 				else s->hot_everywhere = true;
 			}
 		}

@@ -73,7 +73,7 @@ struct HxrNodeDev {
 	int32_t geom;            // geometry table index (CSG operands refer to it)
 	int32_t ref;             // mesh / heightfield index
 	int32_t shader, bump;
-	int32_t cullable;        // cull_lo / cull_hi are valid
+	int32_t cullable;        // 1: cull_lo / cull_hi hold the culling sphere of a bounded geometry; 2: a plane node's world-space side test (c, k, |c|)
 	int32_t needs_uv;        // the node's bump map or a texture in its shader tree reads IntersectionInfo::u / v
 	int32_t identity;        // T.m, T.inv_m and T.tinv_m are exactly the identity (a translate-only node): the products are skipped
 	double p[6];             // analytic parameters of the geometry

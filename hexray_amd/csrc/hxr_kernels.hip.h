@@ -868,11 +868,30 @@ HXR_DEV d3 local_hit_point(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 
 
 // Node::intersect (src/geometry.cpp:196-208) up to the world-space distance
 template <bool COUNT, unsigned F>
-HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, GeomHit& g, double& wdist, const Stacks& st, Tally<COUNT>& tl)
+HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, double reach_limit, GeomHit& g, double& wdist, const Stacks& st, Tally<COUNT>& tl)
 {
 	const HxrNodeDev& N = S.nodes[__builtin_amdgcn_readfirstlane(ni)];   // the node scan is wave-uniform: scalar loads
 	tl.add(HC_NODE);
-	if (N.cullable) {
+	if (N.cullable == 2) {
+		// A plane node.  Plane::intersect (src/geometry.cpp:33-34) misses when the ray starts on one side and does not head for the
+		// plane, and a hit farther than `reach_limit` along the ray cannot matter to the caller (visible(): beyond the segment;
+		// raycast(): beyond the best hit so far).  Both are decided in world space from s(p) = p . c - k, the object-space height of a
+		// point above the plane (c = the y-column of the node's inverse matrix, so s is the very sum Node::intersect forms for
+		// ol.y - py): the ray is clearly heading away, or the piece of it that matters stays clearly on one side.  "Clearly" = by 1e-9
+		// relative, seven orders above rounding; anything closer takes the exact path below.  It pays when EVERY lane of the wave
+		// agrees (like the sphere cull): the shadow turns of a path tracer inside a room of planes (smallpt) skip all its walls.
+		const d3 c = mk3(N.cull_lo[0], N.cull_lo[1], N.cull_lo[2]);
+		const double k = N.cull_hi[0], cn = N.cull_hi[1];
+		const double sA = dot(o, c) - k, h = dot(d, c);
+		const double eps = 1e-9 * (fabs(sA) + fabs(k) + cn), eh = 1e-9 * cn;
+		const bool away = (sA > eps && h > eh) || (sA < -eps && h < -eh);
+		bool far_side = false;
+		if (reach_limit < HXR_INF) {
+			const double sB = sA + h * reach_limit, eb = eps + 1e-9 * fabs(h * reach_limit);
+			far_side = (sA > eps && sB > eb) || (sA < -eps && sB < -eb);
+		}
+		if (!hxr_ballot(!(away || far_side))) return false;
+	} else if (N.cullable) {
 		// World-space rejection: when NO ray of the wave reaches the node's (inflated) world box, the reference's
 		// Node::intersect would return false for every one of them -- after transforming the ray and, for a mesh,
 		// failing the root BBox::testIntersect (src/mesh.cpp:249), which is counted as if it had been made.
@@ -1180,7 +1199,7 @@ HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any
 	for (int ni = 0; ni < S.num_nodes; ni++) {
 		GeomHit g;
 		double w;
-		if (node_query<COUNT, F>(S, ni, o, d, g, w, st, tl) && w < bw) {
+		if (node_query<COUNT, F>(S, ni, o, d, bw, g, w, st, tl) && w < bw) {
 			bw = w;
 			bg = g;
 			node = ni;
