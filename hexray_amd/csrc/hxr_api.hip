@@ -687,7 +687,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (p.layout == HXR_LAYOUT_FRAME && stride < (size_t)p.W * 12) { set_err("row stride smaller than a row"); return HXR_E_INVALID; }
 	const bool counters = fp->collect_counters != 0;
-#if defined(HXR_PHASE_TIMERS) || defined(HXR_LEAF_STATS)
+#if defined(HXR_PHASE_TIMERS) || defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS)
 	const bool want_counter_buffer = true;    // profiling build: the phase clocks land in hxr_counters.reserved_
 #else
 	const bool want_counter_buffer = counters;
@@ -1156,7 +1156,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	s->d_work = (uint32_t*)p;
 	if (s->arena.alloc(sizeof(hxr_counters), &p)) return fail();
 	s->d_counters = (unsigned long long*)p;
-#ifdef HXR_LEAF_STATS
+#if defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS)
 	V.dev_stats = s->d_counters + HC_NUM;
 #endif
 	const HxrSceneDev* dv = nullptr;

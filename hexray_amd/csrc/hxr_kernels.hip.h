@@ -1427,6 +1427,17 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 			const bool any_closest = hxr_ballot(want == Q_CLOSEST) != 0, any_shadow = hxr_ballot(want == Q_SHADOW) != 0;
 			const int serve = (any_closest && any_shadow) ? (shadow_turn ? Q_SHADOW : Q_CLOSEST) : (any_closest ? Q_CLOSEST : Q_SHADOW);
 			shadow_turn = serve == Q_CLOSEST;   // the other kind next time
+#ifdef HXR_TURN_STATS   // developer aid: how full are the turns?  dev_stats[0] turns, [1] lanes still tracing, [2] lanes served, [3] closest turns, [4] lanes served in closest turns
+			{
+				const unsigned long long alive = hxr_ballot(true), served = hxr_ballot(want == serve);
+				if (S.dev_stats && (int)(threadIdx.x & 63) == (int)__builtin_ctzll(alive)) {
+					atomicAdd(S.dev_stats + 0, 1ull);
+					atomicAdd(S.dev_stats + 1, (unsigned long long)__popcll(alive));
+					atomicAdd(S.dev_stats + 2, (unsigned long long)__popcll(served));
+					if (serve == Q_CLOSEST) { atomicAdd(S.dev_stats + 3, 1ull); atomicAdd(S.dev_stats + 4, (unsigned long long)__popcll(served)); }
+				}
+			}
+#endif
 			if (want != serve) continue;
 		}
 		// ---- 1. what does this lane ask the scene?
