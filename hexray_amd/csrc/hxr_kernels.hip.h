@@ -69,6 +69,11 @@ struct f3 { float x, y, z; };
 
 HXR_DEV d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
 HXR_DEV d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+// Pointers the kernels find INSIDE records in HBM (a mesh's vertex arrays, a heightfield's tables, a bitmap's texels) are generic
+// to the compiler, which then emits flat_load (both memory counters, LDS aperture check).  They all point into HBM: say so.
+#define HXR_GLOBAL __attribute__((address_space(1)))
+template <class T> HXR_DEV const HXR_GLOBAL T* in_hbm(const T* p) { return (const HXR_GLOBAL T*)p; }
+HXR_DEV d3 ld3(const HXR_GLOBAL double* p) { return d3{p[0], p[1], p[2]}; }
 HXR_DEV d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 HXR_DEV d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 HXR_DEV d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
@@ -103,6 +108,7 @@ HXR_DEV double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 HXR_DEV f3 mkf(float x, float y, float z) { return f3{x, y, z}; }
 HXR_DEV f3 ldf(const float* p) { return f3{p[0], p[1], p[2]}; }
+HXR_DEV f3 ldf(const HXR_GLOBAL float* p) { return f3{p[0], p[1], p[2]}; }
 HXR_DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 HXR_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 HXR_DEV f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
@@ -454,7 +460,7 @@ HXR_DEV bool triangle_test(const HxrMeshDev& M, const HxrTriHot& T, int id, cons
 {
 	bool ok = true;
 	if (M.backface_culling) {
-		const hxr_triangle& ct = M.tris[id];
+		const HXR_GLOBAL hxr_triangle& ct = in_hbm(M.tris)[id];
 		ok = !(dot(d, ld3(ct.gnormal)) > 0);
 	}
 	// The four sign / magnitude rejections are evaluated without branching between them: the lanes of a
@@ -752,55 +758,107 @@ HXR_DEV bool tri_fast(d3 o, d3 d, d3 A, d3 B, d3 C, double& best)
 HXR_DEV int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
 // Heightfield::intersect, src/heightfield.cpp:106-171
+//
+// Every lane follows the reference's marching sequence step for step; what the wave chooses is WHEN the two triangle
+// tests of a cell run.  They are ~10x the cost of a marching step and only ~0.8 cells per ray need them, so a lane
+// whose cell needs them parks (need_tri) while the other lanes go on marching, and the tests run for all parked lanes
+// together once HXR_HF_TRI_BATCH of them wait or nobody can march any further.
+#ifndef HXR_HF_TRI_BATCH
+#define HXR_HF_TRI_BATCH 24
+#endif
 template <bool COUNT>
 HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& g, Tally<COUNT>& tl)
 {
 	tl.add(HC_HFCALL);
+	tl.template lap<PH_QUERY>();   // profiling builds: marching is charged to the "mesh walk" column, the triangle pairs to "leaf"
 	Box box{ld3(F.bbox_min), ld3(F.bbox_max)};
 	d3 step = d * (1.0 / sqrt(d.x * d.x + d.z * d.z));
 	double dist = box_nearest(box, o, d);
 	d3 p = o + d * (dist + 1e-6);
 	double mx = 1.0 / d.x, mz = 1.0 / d.z;
-	while (box_holds(box, p)) {
-		int x0 = (int)floor(p.x), z0 = (int)floor(p.z);
-		if (x0 < 0 || x0 >= F.W || z0 < 0 || z0 >= F.H) break;
-		if (F.use_optimization) {
-			const float* hm = F.high_map + ((size_t)z0 * F.W + x0) * 16;   // (x0, z0) is in range here: no clamping needed
-			int k = 1;
-			while (k < F.max_k) {
-				tl.add(HC_HFHIGH);
-				if (!(p.y + step.y * (1 << k) > hm[k])) break;
-				k++;
-			}
-			k--;
-			if (k > 0) {
-				p = p + step * (double)(1 << k);
-				continue;
+	bool marching = box_holds(box, p), need_tri = false, found = false;
+	int x0 = 0, z0 = 0;
+	d3 pn = p;
+	for (;;) {
+#ifdef HXR_HF_STATS   // developer aid: lane-steps offered (kd_visits, unused without meshes) against lane-steps taken (box_test_mismatch) in a counting frame
+		tl.add(HC_KD);
+		if (marching && !need_tri) tl.add(HC_BOXMISMATCH);
+#endif
+		if (marching && !need_tri) {
+			x0 = (int)floor(p.x);
+			z0 = (int)floor(p.z);
+			if (x0 < 0 || x0 >= F.W || z0 < 0 || z0 >= F.H) {
+				marching = false;
+			} else {
+				const size_t cell = (size_t)z0 * F.W + x0;   // (x0, z0) is in range here: no clamping needed
+				const float cell_max = in_hbm(F.max_h)[cell];        // issued with the pyramid levels: one memory latency per step instead of one per level
+				int k = 0;
+				if (F.use_optimization && F.max_k > 1) {
+					// the reference probes levels 1, 2, ... one dependent load at a time; the levels of a cell are one 64-byte record, so
+					// fetch levels 0-7 at once and decide in registers (same comparisons, same order, same first failure)
+					const HXR_GLOBAL float* hm = in_hbm(F.high_map) + cell * 16;
+					typedef float Levels4 __attribute__((ext_vector_type(4)));
+					const Levels4 lo = *(const HXR_GLOBAL Levels4*)hm, hi = *(const HXR_GLOBAL Levels4*)(hm + 4);
+					const float lv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+					const int top = F.max_k < 8 ? F.max_k : 8;
+					bool passing = true;   // no branches between the levels: the lanes of a wave stop at different ones
+					k = 1;
+#pragma unroll
+					for (int j = 1; j < 8; j++) {
+						passing = passing & (j < top) & (p.y + step.y * (1 << j) > lv[j]);
+						k += passing ? 1 : 0;
+					}
+					while (k >= 8 && k < F.max_k && p.y + step.y * (1 << k) > hm[k]) k++;
+					tl.add(HC_HFHIGH, k < F.max_k ? k : F.max_k - 1);   // probes made: every passed level plus the failed one
+					k--;
+				}
+				if (k > 0) {
+					p = p + step * (double)(1 << k);
+					marching = box_holds(box, p);
+				} else {
+					double lx = d.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
+					double lz = d.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
+					pn = p + step * (fmin(lx, lz) + 1e-6);
+					tl.add(HC_HFHEIGHT);
+					if (fmin(p.y, pn.y) < cell_max) {
+						need_tri = true;
+					} else {
+						p = pn;
+						marching = box_holds(box, p);
+					}
+				}
 			}
 		}
-		double lx = d.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
-		double lz = d.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
-		d3 pn = p + step * (fmin(lx, lz) + 1e-6);
-		tl.add(HC_HFHEIGHT);
-		if (fmin(p.y, pn.y) < F.max_h[(size_t)z0 * F.W + x0]) {
+		const uint64_t waiting = hxr_ballot(need_tri);
+		if (hxr_ballot(marching && !need_tri) != 0 && __popcll(waiting) < HXR_HF_TRI_BATCH) continue;
+		if (waiting == 0) break;
+		tl.template lap<PH_MESH>();
+		if (need_tri) {
 			int x1 = clampi(x0 + 1, F.W - 1), z1 = clampi(z0 + 1, F.H - 1);   // getHeight clamps (src/heightfield.cpp:30-37)
 			tl.add(HC_HFHEIGHT, 4);
 			tl.add(HC_HFTRI, 2);
-			d3 A = mk3(x0, F.heights[(size_t)z0 * F.W + x0], z0);
-			d3 B = mk3(x0 + 1, F.heights[(size_t)z0 * F.W + x1], z0);
-			d3 C = mk3(x0 + 1, F.heights[(size_t)z1 * F.W + x1], z0 + 1);
-			d3 D = mk3(x0, F.heights[(size_t)z1 * F.W + x0], z0 + 1);
+			const HXR_GLOBAL float* hs = in_hbm(F.heights);
+			d3 A = mk3(x0, hs[(size_t)z0 * F.W + x0], z0);
+			d3 B = mk3(x0 + 1, hs[(size_t)z0 * F.W + x1], z0);
+			d3 C = mk3(x0 + 1, hs[(size_t)z1 * F.W + x1], z0 + 1);
+			d3 D = mk3(x0, hs[(size_t)z1 * F.W + x0], z0 + 1);
 			double best = HXR_INF;
 			bool b1 = tri_fast(o, d, A, B, D, best);
 			bool b2 = tri_fast(o, d, B, C, D, best);
+			need_tri = false;
 			if (b1 || b2) {
 				g.t = best;
-				return true;
+				found = true;
+				marching = false;
+			} else {
+				p = pn;
+				marching = box_holds(box, p);
 			}
 		}
-		p = pn;
+		tl.template lap<PH_LEAF>();
 	}
-	return false;
+	tl.template lap<PH_MESH>();
+	return found;
 }
 
 // Heightfield::getNormal, src/heightfield.cpp:83-104
@@ -811,7 +869,7 @@ HXR_DEV d3 heightfield_normal(const HxrHeightfieldDev& F, float x, float y)
 	int x1 = min(F.W - 1, x0 + 1), y1 = min(F.H - 1, y0 + 1);
 	x0 = clampi(x0, F.W - 1);
 	y0 = clampi(y0, F.H - 1);
-	const double* n = F.normals;
+	const HXR_GLOBAL double* n = in_hbm(F.normals);
 	d3 v = ld3(n + ((size_t)y0 * F.W + x0) * 3) * (double)((1 - p) * (1 - q)) + ld3(n + ((size_t)y0 * F.W + x1) * 3) * (double)(p * (1 - q)) +
 	       ld3(n + ((size_t)y1 * F.W + x0) * 3) * (double)((1 - p) * q) + ld3(n + ((size_t)y1 * F.W + x1) * 3) * (double)(p * q);
 	return unit(v);
@@ -976,16 +1034,18 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 		}
 		case HXR_GEOM_MESH: if constexpr ((F & HXR_F_MESH) != 0) {   // Mesh::intersectTriangle's attribute half, src/mesh.cpp:196-218
 			const HxrMeshDev& M = S.meshes[N.ref];
-			const hxr_triangle& t = M.tris[g.tri];
+			const HXR_GLOBAL hxr_triangle& t = in_hbm(M.tris)[g.tri];
+			const HXR_GLOBAL double* uvs = in_hbm(M.uvs);
 			tl.add(HC_MESHHIT);
-			d3 tA = ld3(M.uvs + 3 * (size_t)t.t[0]), tB = ld3(M.uvs + 3 * (size_t)t.t[1]), tC = ld3(M.uvs + 3 * (size_t)t.t[2]);
+			d3 tA = ld3(uvs + 3 * (size_t)t.t[0]), tB = ld3(uvs + 3 * (size_t)t.t[1]), tC = ld3(uvs + 3 * (size_t)t.t[2]);
 			d3 tc = tA + (tB - tA) * g.l2 + (tC - tA) * g.l3;
 			sf.u = tc.x;
 			sf.v = tc.y;
 			if (M.faceted) {
 				n = ld3(t.gnormal);
 			} else {
-				d3 nA = ld3(M.normals + 3 * (size_t)t.n[0]), nB = ld3(M.normals + 3 * (size_t)t.n[1]), nC = ld3(M.normals + 3 * (size_t)t.n[2]);
+				const HXR_GLOBAL double* ns = in_hbm(M.normals);
+				d3 nA = ld3(ns + 3 * (size_t)t.n[0]), nB = ld3(ns + 3 * (size_t)t.n[1]), nC = ld3(ns + 3 * (size_t)t.n[2]);
 				n = unit(nA + (nB - nA) * g.l2 + (nC - nA) * g.l3);
 			}
 			sf.dNdx = ld3(t.dNdx);
@@ -1088,7 +1148,7 @@ HXR_DEV f3 bitmap_bilinear(const HxrBitmapDev& b, float x, float y)   // Bitmap:
 	if (tx < 0 || ty < 0) return mkf(0, 0, 0);
 	int tx1 = (tx + 1) % w, ty1 = (ty + 1) % h;
 	float p = x - tx, q = y - ty;
-	const float* t = b.texels;
+	const HXR_GLOBAL float* t = in_hbm(b.texels);
 	return ldf(t + ((size_t)ty * w + tx) * 3) * ((1.0f - p) * (1.0f - q)) + ldf(t + ((size_t)ty * w + tx1) * 3) * (p * (1.0f - q)) +
 	       ldf(t + ((size_t)ty1 * w + tx) * 3) * ((1.0f - p) * q) + ldf(t + ((size_t)ty1 * w + tx1) * 3) * (p * q);
 }
