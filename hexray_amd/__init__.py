@@ -45,7 +45,7 @@ COUNTER_FIELDS = [
 ]
 
 
-ACCEL_REFERENCE, ACCEL_SAH = 0, 1
+ACCEL_REFERENCE, ACCEL_SAH, ACCEL_REFERENCE_DEVICE_BUILD = 0, 1, 2
 
 
 class SceneOptions(ctypes.Structure):
@@ -132,12 +132,13 @@ class HostScene:
     (reference src/scene.cpp:764-778, src/camera.h:57-72), so overrides are expressed the same way.
     """
 
-    def __init__(self, path: str, overlay: str = "", gpu_heightfield_tables: bool = False):
+    def __init__(self, path: str, overlay: str = "", gpu_heightfield_tables: bool = False, gpu_kd_build: bool = False):
         """``gpu_heightfield_tables``: leave the heightfield maxima tables to the render module (it builds them on the GPU); such a
-        scene is for the HIP module only -- the CPU oracle needs the host's tables."""
+        scene is for the HIP module only -- the CPU oracle needs the host's tables.
+        ``gpu_kd_build``: skip Mesh::buildKD on the host; create the DeviceScene with ACCEL_REFERENCE_DEVICE_BUILD (or ACCEL_SAH)."""
         lib = host_lib()
         err = ctypes.create_string_buffer(1024)
-        self._h = lib.hxh_scene_load_ex(os.fsencode(path), overlay.encode(), 1 if gpu_heightfield_tables else 0, err, len(err))
+        self._h = lib.hxh_scene_load_ex(os.fsencode(path), overlay.encode(), (1 if gpu_heightfield_tables else 0) | (2 if gpu_kd_build else 0), err, len(err))
         if not self._h:
             raise ValueError(f"cannot load scene {path}: {err.value.decode(errors='replace')}")
         self.path = path
@@ -266,6 +267,9 @@ def hip_lib():
         lib.hxr_scene_create_ex.restype = c_void_p
         lib.hxr_scene_create_ex.argtypes = [c_void_p, POINTER(SceneOptions)]
         lib.hxr_scene_tree_stats.argtypes = [c_void_p, c_int, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(c_int)]
+        lib.hxr_kd_build_device.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64),
+                                            POINTER(c_int), POINTER(c_double)]
+        lib.hxr_sah_build.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(c_int)]
         lib.hxr_scene_update_camera.argtypes = [c_void_p, c_void_p]
         lib.hxr_scene_verify_tables.argtypes = [c_void_p, c_void_p, POINTER(ctypes.c_int64)]
         lib.hxr_render.argtypes = [c_void_p, POINTER(FrameParams), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
@@ -324,6 +328,21 @@ def init(device_id: int = 0):
         raise HipError("no gfx950 device visible: the render path has no CPU fallback")
     _check(lib.hxr_init(device_id), "hxr_init")
     _initialised_device = device_id
+
+
+KD_NODE_DTYPE = np.dtype([("axis", "<i4"), ("first", "<i4"), ("count", "<i4"), ("parent", "<i4"), ("split", "<f8")])   # hxr_kd_node
+
+
+def kd_build_device(host_scene: "HostScene", mesh: int = 0):
+    """Mesh::buildKD on the GPU (hxr_kd_build_device): the reference's tree of mesh ``mesh`` of the scene, built from its triangles.
+    Returns (nodes [KD_NODE_DTYPE], leaf_indices [int32], max_depth, build_ms)."""
+    lib = hip_lib()
+    nn, nl, depth, ms = ctypes.c_int64(), ctypes.c_int64(), c_int(), c_double()
+    _check(lib.hxr_kd_build_device(host_scene.desc, mesh, None, 0, None, 0, nn, nl, depth, ms), "hxr_kd_build_device")
+    nodes = np.zeros(nn.value, dtype=KD_NODE_DTYPE)
+    leaf = np.zeros(max(1, nl.value), dtype=np.int32)
+    _check(lib.hxr_kd_build_device(host_scene.desc, mesh, nodes.ctypes.data, nn.value, leaf.ctypes.data, leaf.size, nn, nl, depth, ms), "hxr_kd_build_device")
+    return nodes, leaf[:nl.value], depth.value, ms.value
 
 
 class DeviceScene:

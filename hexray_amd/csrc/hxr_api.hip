@@ -15,6 +15,7 @@
 #include "hexray_hip.h"
 #include "hxr_kernels.hip.h"
 #include "hxr_accel.h"
+#include "hxr_kd_build.h"
 
 #include "hxr_variants.h"
 // compiled in hxr_kernels_mesh.hip / hxr_kernels_mesh2.hip / hxr_kernels_heightfield.hip with their own flags
@@ -87,6 +88,7 @@ struct hxr_scene {
 	unsigned features = 0;          // HXR_F_* geometry kinds present among the nodes
 	struct TreeStats { int64_t nodes, leaf_entries; int depth; };
 	std::vector<TreeStats> tree_stats;   // per mesh: the tree actually walked
+	double kd_build_ms = 0;              // HXR_ACCEL_REFERENCE_DEVICE_BUILD: time of the kd builds on the GPU, all meshes
 	// per-frame scratch, grown on demand
 	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
 	float* d_scratch = nullptr;     size_t scratch_bytes = 0;  // sharded-AA full frame
@@ -887,7 +889,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (opt) {
 		if (opt->struct_size < sizeof(hxr_scene_options)) { set_err("hxr_scene_options.struct_size too small"); return nullptr; }
 		accel = opt->accel;
-		if (accel != HXR_ACCEL_REFERENCE && accel != HXR_ACCEL_SAH) { set_err("unknown acceleration structure %d", accel); return nullptr; }
+		if (accel != HXR_ACCEL_REFERENCE && accel != HXR_ACCEL_SAH && accel != HXR_ACCEL_REFERENCE_DEVICE_BUILD) { set_err("unknown acceleration structure %d", accel); return nullptr; }
 	}
 	const bool adaptive = !(opt && opt->no_adaptive_schedule) && !getenv("HXR_NO_ADAPTIVE_SCHEDULE");
 	hxr_scene* s = new hxr_scene;
@@ -931,7 +933,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		memcpy(o.bbox_max, m.bbox_max, sizeof o.bbox_max);
 		o.faceted = m.faceted;
 		o.backface_culling = m.backface_culling;
-		o.has_kd = m.has_kd && m.num_kd_nodes > 0;
+		o.has_kd = m.has_kd && (m.num_kd_nodes > 0 || accel != HXR_ACCEL_REFERENCE);   // a descriptor without trees (HXH_GPU_KD_BUILD): the module builds them
 		o.num_triangles = (int32_t)m.num_triangles;
 		const hxr_kd_node* nodes = d->kd_nodes + m.first_kd_node;
 		const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
@@ -947,6 +949,19 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 			leaf_idx = sah.leaf_indices.data();
 			num_nodes = (int64_t)sah.nodes.size();
 			num_leaf_entries = (int64_t)sah.leaf_indices.size();
+		}
+		hxr_kd::DeviceBuiltTree built;
+		if (accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD && o.has_kd) {   // Mesh::buildKD as kernels, over the tables uploaded above
+			char why[256] = "";
+			if (hxr_kd::build_reference_tree(d_tris + m.first_triangle, m.num_triangles, d_f64 + m.first_vertex * 3, m.bbox_min, m.bbox_max, built, why, sizeof why)) {
+				set_err("kd build of mesh %lld: %s", (long long)i, why);
+				return fail();
+			}
+			nodes = built.nodes.data();
+			leaf_idx = built.leaf_indices.data();
+			num_nodes = (int64_t)built.nodes.size();
+			num_leaf_entries = (int64_t)built.leaf_indices.size();
+			s->kd_build_ms += built.build_ms;
 		}
 		int depth = append_mesh_tables(d, m, nodes, num_nodes, leaf_idx, o, all_kd, all_boxes, all_hot, all_ids);
 		s->tree_stats.push_back({num_nodes, num_leaf_entries, depth});
@@ -1468,6 +1483,46 @@ int hxr_sah_build(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t
 	if (num_nodes) *num_nodes = (int64_t)t.nodes.size();
 	if (num_leaf) *num_leaf = (int64_t)t.leaf_indices.size();
 	if (max_depth) *max_depth = t.max_depth;
+	if (!nodes && !leaf_indices) return 0;
+	if (!nodes || !leaf_indices || max_nodes < (int64_t)t.nodes.size() || max_leaf < (int64_t)t.leaf_indices.size()) { set_err("output arrays too small"); return HXR_E_INVALID; }
+	memcpy(nodes, t.nodes.data(), t.nodes.size() * sizeof(hxr_kd_node));
+	if (!t.leaf_indices.empty()) memcpy(leaf_indices, t.leaf_indices.data(), t.leaf_indices.size() * sizeof(int32_t));
+	return 0;
+}
+
+int hxr_kd_build_device(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf, int64_t* num_nodes,
+                        int64_t* num_leaf, int* max_depth, double* build_ms)
+{
+	if (g_device < 0) { set_err("hxr_init has not been called"); return HXR_E_INVALID; }
+	if (!d || mesh < 0 || mesh >= d->num_meshes) { set_err("no such mesh"); return HXR_E_INVALID; }
+	const hxr_mesh& m = d->meshes[mesh];
+	if (m.first_triangle < 0 || m.num_triangles < 0 || m.first_triangle + m.num_triangles > d->num_triangles || m.first_vertex < 0 || m.num_vertices < 0 ||
+	    (m.first_vertex + m.num_vertices) * 3 > d->f64_pool_size) { set_err("bad mesh ranges"); return HXR_E_INVALID; }
+	for (int64_t i = 0; i < m.num_triangles; i++)
+		for (int k = 0; k < 3; k++)
+			if (d->triangles[m.first_triangle + i].v[k] < 0 || d->triangles[m.first_triangle + i].v[k] >= m.num_vertices) { set_err("triangle %lld refers to a vertex outside the mesh", (long long)i); return HXR_E_INVALID; }
+	HIP_TRY(hipSetDevice(g_device));
+	hxr_triangle* d_tris = nullptr;
+	double* d_verts = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_tris, std::max<size_t>(1, (size_t)m.num_triangles) * sizeof(hxr_triangle)));
+	if (hipMalloc((void**)&d_verts, std::max<size_t>(1, (size_t)m.num_vertices * 3) * sizeof(double)) != hipSuccess) { (void)hipFree(d_tris); set_err("out of device memory"); return HXR_E_HIP; }
+	int rc = 0;
+	hxr_kd::DeviceBuiltTree t;
+	char why[256] = "";
+	if (hipMemcpy(d_tris, d->triangles + m.first_triangle, (size_t)m.num_triangles * sizeof(hxr_triangle), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_verts, d->f64_pool + m.first_vertex * 3, (size_t)m.num_vertices * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+		set_err("upload of the mesh failed");
+		rc = HXR_E_HIP;
+	} else if ((rc = hxr_kd::build_reference_tree(d_tris, m.num_triangles, d_verts, m.bbox_min, m.bbox_max, t, why, sizeof why)) != 0) {
+		set_err("kd build: %s", why);
+	}
+	(void)hipFree(d_tris);
+	(void)hipFree(d_verts);
+	if (rc) return rc;
+	if (num_nodes) *num_nodes = (int64_t)t.nodes.size();
+	if (num_leaf) *num_leaf = (int64_t)t.leaf_indices.size();
+	if (max_depth) *max_depth = t.max_depth;
+	if (build_ms) *build_ms = t.build_ms;
 	if (!nodes && !leaf_indices) return 0;
 	if (!nodes || !leaf_indices || max_nodes < (int64_t)t.nodes.size() || max_leaf < (int64_t)t.leaf_indices.size()) { set_err("output arrays too small"); return HXR_E_INVALID; }
 	memcpy(nodes, t.nodes.data(), t.nodes.size() * sizeof(hxr_kd_node));

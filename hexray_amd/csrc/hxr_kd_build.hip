@@ -1,0 +1,379 @@
+// Mesh::buildKD on the GPU; see hxr_kd_build.h.
+//
+// One kernel launch per tree level.  A level is a list of tasks {node, box, triangle list, depth}; one workgroup takes
+// one task: a task below 20 triangles or past depth 64 writes its leaf, any other splits its box at the midpoint, runs
+// BBox::intersectTriangle of every triangle of its list against both halves (one triangle per lane) and writes the two
+// child lists with a workgroup-wide stable partition (ballot + popcount ranks), so every list keeps the order the
+// reference's push_back loop gives it (src/mesh.cpp:108-116).  Child tasks, child node pairs, list space and leaf space
+// are claimed with one atomicAdd each; the host reads the task count back after each level (it sizes the next launch and
+// sees the end of the build and any capacity overflow, which restarts the build with larger buffers).  The atomics make
+// the device-side numbering of nodes and leaf lists vary from run to run; the copy back renumbers the tree in the host
+// builder's order (pre-order child pairs, depth-first leaf lists), which makes the result deterministic and directly
+// comparable with a host-built tree.
+//
+// Scope: the work of a task is not split across workgroups, so the first levels of a mesh (few tasks, long lists) run on
+// a few CUs -- 36 rounds of 256 triangles for the root of the 9120-triangle teapot.  For the reference's meshes the whole
+// build is a few hundred microseconds of device time plus one ~10-20 us hand-shake per level.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "hxr_kd_build.h"
+
+namespace hxr_kd {
+namespace {
+
+#define KD_BLOCK 256
+#define KD_LEAF_BELOW 20   // TRIANGLES_PER_LEAF, src/mesh.cpp:97
+#define KD_MAX_DEPTH 64    // MAX_TREE_DEPTH, src/mesh.cpp:97 (a node deeper than this is a leaf)
+
+struct KdTask {   // 64 B
+	double lo[3], hi[3];
+	int32_t node, first, count, depth;
+};
+
+struct KdCtl {
+	uint32_t side[2][2];   // per task-list side: {number of tasks, ints of list space claimed}
+	uint32_t node_cursor, leaf_cursor, error, max_depth;
+};
+
+struct KdCaps { uint32_t tasks, list, nodes, leaf; };
+
+struct P3 { double v[3]; };
+
+__device__ inline P3 sub(const P3& a, const P3& b) { return P3{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]}}; }
+__device__ inline P3 neg(const P3& a) { return P3{{-a.v[0], -a.v[1], -a.v[2]}}; }
+__device__ inline double dot(const P3& a, const P3& b) { return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2]; }
+__device__ inline P3 cross(const P3& a, const P3& b)
+{
+	return P3{{a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]}};
+}
+
+struct BoxD {
+	double lo[3], hi[3];
+	// BBox::inside, borders widened by 1e-6 (src/bbox.h:78-85)
+	__device__ bool holds(const P3& p) const
+	{
+		return lo[0] - 1e-6 <= p.v[0] && p.v[0] <= hi[0] + 1e-6 && lo[1] - 1e-6 <= p.v[1] && p.v[1] <= hi[1] + 1e-6 && lo[2] - 1e-6 <= p.v[2] &&
+		       p.v[2] <= hi[2] + 1e-6;
+	}
+	// BBox::testIntersect (src/bbox.h:94-141); `d` need not be unit length
+	__device__ bool hit_by(const P3& o, const P3& d) const
+	{
+		if (holds(o)) return true;
+		for (int a = 0; a < 3; a++) {
+			if ((d.v[a] < 0 && o.v[a] < lo[a]) || (d.v[a] > 0 && o.v[a] > hi[a])) return false;
+			if (fabs(d.v[a]) < 1e-9) continue;
+			const double inv = 1 / d.v[a];
+			const int u = (a == 0) ? 1 : 0, v = (a == 2) ? 1 : 2;
+			for (int w = 0; w < 2; w++) {
+				const double t = ((w ? hi[a] : lo[a]) - o.v[a]) * inv;
+				if (t < 0) break;   // near wall behind the origin: the far wall of this axis is skipped too
+				const double pu = o.v[u] + d.v[u] * t;
+				if (lo[u] <= pu && pu <= hi[u]) {
+					const double pv = o.v[v] + d.v[v] * t;
+					if (lo[v] <= pv && pv <= hi[v]) return true;
+				}
+			}
+		}
+		return false;
+	}
+};
+
+// intersectTriangleFast (src/mesh.cpp:131-170)
+__device__ bool segment_hits_triangle(const P3& o, const P3& d, const P3& A, const P3& B, const P3& C, double& best)
+{
+	const P3 AB = sub(B, A), AC = sub(C, A), nd = neg(d), H = sub(o, A);
+	const P3 N = cross(AB, AC);
+	const double den = dot(N, nd);
+	if (fabs(den) < 1e-12) return false;
+	const double r = 1 / den;   // the host builder is compiled with the reference's Release flags (-ffast-math): one reciprocal, three products
+	const double l2 = dot(cross(H, AC), nd) * r;
+	const double l3 = dot(cross(AB, H), nd) * r;
+	const double g = dot(N, H) * r;
+	if (g < 0 || g > best) return false;
+	if (l2 < 0 || l2 > 1 || l3 < 0 || l3 > 1 || l2 + l3 > 1) return false;
+	best = g;
+	return true;
+}
+
+__device__ inline double sign_of(double x) { return x > 0 ? +1 : -1; }
+
+// BBox::intersectTriangle (src/bbox.h:177-207): a vertex inside, an edge through the box, a box edge through the triangle
+__device__ bool box_overlaps_triangle(const BoxD& b, const P3& A, const P3& B, const P3& C)
+{
+	if (b.holds(A) || b.holds(B) || b.holds(C)) return true;
+	const P3 t[3] = {A, B, C};
+	for (int i = 0; i < 3; i++)
+		for (int j = i + 1; j < 3; j++)
+			if (b.hit_by(t[i], sub(t[j], t[i])) && b.hit_by(t[j], sub(t[i], t[j]))) return true;
+	const P3 N = cross(sub(B, A), sub(C, A));
+	const double D = dot(A, N);
+	for (int mask = 0; mask < 7; mask++)
+		for (int j = 0; j < 3; j++) {
+			if (mask & (1 << j)) continue;
+			const P3 s{{(mask & 1) ? b.hi[0] : b.lo[0], (mask & 2) ? b.hi[1] : b.lo[1], (mask & 4) ? b.hi[2] : b.lo[2]}};
+			P3 e = s;
+			e.v[j] = b.hi[j];
+			if (sign_of(dot(s, N) - D) != sign_of(dot(e, N) - D)) {
+				double reach = 1.0000001;
+				if (segment_hits_triangle(s, sub(e, s), A, B, C, reach)) return true;
+			}
+		}
+	return false;
+}
+
+__global__ void kd_iota_kernel(int32_t* list, uint32_t n)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) list[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, const KdTask* __restrict__ tasks_in,
+                                                            uint32_t n_in, const int32_t* __restrict__ list_in, KdTask* __restrict__ tasks_out,
+                                                            int32_t* __restrict__ list_out, hxr_kd_node* __restrict__ nodes, int32_t* __restrict__ leaf_idx,
+                                                            KdCtl* __restrict__ ctl, int side_out, KdCaps caps)
+{
+	__shared__ uint32_t s_claim[4];               // leaf: {first}; split: {list base, first child node, task slot}; [3] = 1 when a capacity ran out
+	__shared__ uint32_t s_left[KD_BLOCK / 64], s_right[KD_BLOCK / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for (uint32_t ti = blockIdx.x; ti < n_in; ti += gridDim.x) {
+		const KdTask T = tasks_in[ti];
+		const uint32_t count = (uint32_t)T.count;
+		__syncthreads();   // the previous task's claims have been read by everyone
+		if (T.count < KD_LEAF_BELOW || T.depth > KD_MAX_DEPTH) {
+			if (tid == 0) {
+				const uint32_t first = atomicAdd(&ctl->leaf_cursor, count);
+				const bool fits = first + count <= caps.leaf;
+				if (!fits) atomicOr(&ctl->error, 1u);
+				s_claim[0] = first;
+				s_claim[3] = fits ? 0 : 1;
+				atomicMax(&ctl->max_depth, (uint32_t)T.depth);
+				hxr_kd_node& n = nodes[T.node];   // `parent` was written when the pair was claimed
+				n.axis = 3;
+				n.first = (int32_t)first;
+				n.count = T.count;
+				n.split = 0;
+			}
+			__syncthreads();
+			if (s_claim[3]) continue;
+			const uint32_t first = s_claim[0];
+			for (uint32_t i = tid; i < count; i += KD_BLOCK) leaf_idx[first + i] = list_in[T.first + i];
+			continue;
+		}
+		if (tid == 0) {
+			const uint32_t base = atomicAdd(&ctl->side[side_out][1], 2 * count);
+			const uint32_t kids = atomicAdd(&ctl->node_cursor, 2u);
+			const uint32_t slot = atomicAdd(&ctl->side[side_out][0], 2u);
+			const bool fits = base + 2 * count <= caps.list && kids + 2 <= caps.nodes && slot + 2 <= caps.tasks;
+			if (!fits) atomicOr(&ctl->error, 1u);
+			s_claim[0] = base;
+			s_claim[1] = kids;
+			s_claim[2] = slot;
+			s_claim[3] = fits ? 0 : 1;
+		}
+		__syncthreads();
+		if (s_claim[3]) continue;
+		const uint32_t base = s_claim[0], kids = s_claim[1], slot = s_claim[2];
+		const int axis = T.depth % 3;
+		const double split = T.lo[axis] + (T.hi[axis] - T.lo[axis]) * 0.5;
+		BoxD L, R;
+		for (int c = 0; c < 3; c++) { L.lo[c] = R.lo[c] = T.lo[c]; L.hi[c] = R.hi[c] = T.hi[c]; }   // BBox::split, src/bbox.h:210-216
+		L.hi[axis] = split;
+		R.lo[axis] = split;
+		uint32_t n_left = 0, n_right = 0;
+		for (uint32_t c = 0; c < count; c += KD_BLOCK) {
+			const uint32_t i = c + tid;
+			int tri = 0;
+			bool in_left = false, in_right = false;
+			if (i < count) {
+				tri = list_in[T.first + i];
+				const hxr_triangle& t = tris[tri];
+				P3 A, B, C;
+				for (int k = 0; k < 3; k++) {
+					A.v[k] = verts[3 * (size_t)t.v[0] + k];
+					B.v[k] = verts[3 * (size_t)t.v[1] + k];
+					C.v[k] = verts[3 * (size_t)t.v[2] + k];
+				}
+				in_left = box_overlaps_triangle(L, A, B, C);
+				in_right = box_overlaps_triangle(R, A, B, C);
+			}
+			const unsigned long long bl = __ballot(in_left), br = __ballot(in_right), below = (1ull << lane) - 1;
+			if (lane == 0) { s_left[wave] = (uint32_t)__popcll(bl); s_right[wave] = (uint32_t)__popcll(br); }
+			__syncthreads();
+			uint32_t before_l = 0, before_r = 0, total_l = 0, total_r = 0;
+			for (int w = 0; w < KD_BLOCK / 64; w++) {
+				if (w < wave) { before_l += s_left[w]; before_r += s_right[w]; }
+				total_l += s_left[w];
+				total_r += s_right[w];
+			}
+			if (in_left) list_out[base + n_left + before_l + (uint32_t)__popcll(bl & below)] = tri;
+			if (in_right) list_out[base + count + n_right + before_r + (uint32_t)__popcll(br & below)] = tri;
+			n_left += total_l;
+			n_right += total_r;
+			__syncthreads();   // the wave sums are rewritten by the next round
+		}
+		if (tid == 0) {
+			hxr_kd_node& n = nodes[T.node];
+			n.axis = axis;
+			n.first = (int32_t)kids;
+			n.count = 0;
+			n.split = split;
+			nodes[kids].parent = nodes[kids + 1].parent = T.node;
+			KdTask a, b;
+			for (int c = 0; c < 3; c++) { a.lo[c] = L.lo[c]; a.hi[c] = L.hi[c]; b.lo[c] = R.lo[c]; b.hi[c] = R.hi[c]; }
+			a.node = (int32_t)kids;      a.first = (int32_t)base;           a.count = (int32_t)n_left;  a.depth = T.depth + 1;
+			b.node = (int32_t)kids + 1;  b.first = (int32_t)(base + count); b.count = (int32_t)n_right; b.depth = T.depth + 1;
+			tasks_out[slot] = a;
+			tasks_out[slot + 1] = b;
+		}
+	}
+}
+
+void say(char* err, size_t n, const char* fmt, ...)
+{
+	if (!err || !n) return;
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(err, n, fmt, ap);
+	va_end(ap);
+}
+
+struct DeviceBuffers {
+	KdTask* tasks[2] = {nullptr, nullptr};
+	int32_t* lists[2] = {nullptr, nullptr};
+	hxr_kd_node* nodes = nullptr;
+	int32_t* leaf = nullptr;
+	KdCtl* ctl = nullptr;
+	~DeviceBuffers()
+	{
+		for (int i = 0; i < 2; i++) { if (tasks[i]) (void)hipFree(tasks[i]); if (lists[i]) (void)hipFree(lists[i]); }
+		if (nodes) (void)hipFree(nodes);
+		if (leaf) (void)hipFree(leaf);
+		if (ctl) (void)hipFree(ctl);
+	}
+};
+
+#define KD_TRY(expr)                                                                                           \
+	do {                                                                                                       \
+		hipError_t e_ = (expr);                                                                                \
+		if (e_ != hipSuccess) {                                                                                \
+			say(err, err_len, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
+			return HXR_E_HIP;                                                                                  \
+		}                                                                                                      \
+	} while (0)
+
+// one attempt with the given capacities; *overflow tells the caller to try again with larger ones
+int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const double lo[3], const double hi[3], const KdCaps& caps, DeviceBuiltTree& out,
+            bool* overflow, char* err, size_t err_len)
+{
+	*overflow = false;
+	DeviceBuffers B;
+	for (int i = 0; i < 2; i++) {
+		KD_TRY(hipMalloc((void**)&B.tasks[i], (size_t)caps.tasks * sizeof(KdTask)));
+		KD_TRY(hipMalloc((void**)&B.lists[i], (size_t)caps.list * sizeof(int32_t)));
+	}
+	KD_TRY(hipMalloc((void**)&B.nodes, (size_t)caps.nodes * sizeof(hxr_kd_node)));
+	KD_TRY(hipMalloc((void**)&B.leaf, (size_t)caps.leaf * sizeof(int32_t)));
+	KD_TRY(hipMalloc((void**)&B.ctl, sizeof(KdCtl)));
+
+	const auto t0 = std::chrono::steady_clock::now();
+	KdTask root;
+	for (int c = 0; c < 3; c++) { root.lo[c] = lo[c]; root.hi[c] = hi[c]; }
+	root.node = 0; root.first = 0; root.count = (int32_t)n; root.depth = 0;
+	hxr_kd_node root_node;
+	memset(&root_node, 0, sizeof root_node);
+	root_node.parent = -1;
+	KdCtl ctl;
+	memset(&ctl, 0, sizeof ctl);
+	ctl.side[0][0] = 1;
+	ctl.side[0][1] = n;
+	ctl.node_cursor = 1;
+	KD_TRY(hipMemcpy(B.tasks[0], &root, sizeof root, hipMemcpyHostToDevice));
+	KD_TRY(hipMemcpy(B.nodes, &root_node, sizeof root_node, hipMemcpyHostToDevice));
+	KD_TRY(hipMemcpy(B.ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
+	if (n) hipLaunchKernelGGL(kd_iota_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, nullptr, B.lists[0], n);
+
+	uint32_t n_in = 1;
+	int side_in = 0, levels = 0;
+	while (n_in > 0) {
+		const int side_out = side_in ^ 1;
+		KD_TRY(hipMemsetAsync(&B.ctl->side[side_out][0], 0, 2 * sizeof(uint32_t), nullptr));
+		hipLaunchKernelGGL(kd_level_kernel, dim3(n_in < 4096 ? n_in : 4096), dim3(KD_BLOCK), 0, nullptr, d_tris, d_verts, B.tasks[side_in], n_in, B.lists[side_in],
+		                   B.tasks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps);
+		KD_TRY(hipGetLastError());
+		KD_TRY(hipMemcpy(&ctl, B.ctl, sizeof ctl, hipMemcpyDeviceToHost));   // the per-level hand-shake (synchronises)
+		levels++;
+		if (ctl.error) { *overflow = true; return 0; }
+		n_in = ctl.side[side_out][0];
+		side_in = side_out;
+		if (levels > KD_MAX_DEPTH + 2) { say(err, err_len, "kd build did not terminate"); return HXR_E_INVALID; }
+	}
+	out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	out.levels = levels;
+	out.max_depth = (int)ctl.max_depth;
+
+	// copy back and renumber in the host builder's order: a node's child pair is appended when the node is split, subtrees left first
+	std::vector<hxr_kd_node> dev_nodes(ctl.node_cursor);
+	std::vector<int32_t> dev_leaf(ctl.leaf_cursor);
+	KD_TRY(hipMemcpy(dev_nodes.data(), B.nodes, dev_nodes.size() * sizeof(hxr_kd_node), hipMemcpyDeviceToHost));
+	if (!dev_leaf.empty()) KD_TRY(hipMemcpy(dev_leaf.data(), B.leaf, dev_leaf.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+	out.nodes.clear();
+	out.leaf_indices.clear();
+	out.nodes.reserve(dev_nodes.size());
+	out.leaf_indices.reserve(dev_leaf.size());
+	out.nodes.resize(1);
+	out.nodes[0].parent = -1;
+	struct Visit { int32_t dev, host; };
+	std::vector<Visit> todo{{0, 0}};
+	while (!todo.empty()) {
+		const Visit v = todo.back();
+		todo.pop_back();
+		const hxr_kd_node& src = dev_nodes[(size_t)v.dev];
+		if (src.axis == 3) {
+			hxr_kd_node& dst = out.nodes[(size_t)v.host];
+			dst.axis = 3;
+			dst.first = (int32_t)out.leaf_indices.size();
+			dst.count = src.count;
+			dst.split = 0;
+			out.leaf_indices.insert(out.leaf_indices.end(), dev_leaf.begin() + src.first, dev_leaf.begin() + src.first + src.count);
+			continue;
+		}
+		const int32_t first = (int32_t)out.nodes.size();
+		out.nodes.resize(out.nodes.size() + 2);
+		out.nodes[(size_t)first].parent = out.nodes[(size_t)first + 1].parent = v.host;
+		hxr_kd_node& dst = out.nodes[(size_t)v.host];
+		dst.axis = src.axis;
+		dst.first = first;
+		dst.count = 0;
+		dst.split = src.split;
+		todo.push_back({src.first + 1, first + 1});
+		todo.push_back({src.first, first});   // left subtree first
+	}
+	return 0;
+}
+
+}  // namespace
+
+int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
+                         DeviceBuiltTree& out, char* err, size_t err_len)
+{
+	if (num_triangles < 0 || num_triangles > (1ll << 26)) { say(err, err_len, "kd build: %lld triangles not supported", (long long)num_triangles); return HXR_E_INVALID; }
+	const uint32_t n = (uint32_t)num_triangles;
+	// the reference's meshes end at 0.2-0.7 nodes and 2.5-5 leaf entries per triangle; a level's lists hold at most twice its parent level's
+	uint64_t scale = 1;
+	for (int tries = 0; tries < 4; tries++, scale *= 4) {
+		const uint64_t tasks = std::min<uint64_t>((4ull * n + 4096) * scale, 1ull << 27), list = std::min<uint64_t>((24ull * n + 65536) * scale, 1ull << 31),
+		               nodes = std::min<uint64_t>((8ull * n + 4096) * scale, 1ull << 28), leaf = std::min<uint64_t>((32ull * n + 65536) * scale, 1ull << 31);
+		KdCaps caps{(uint32_t)tasks, (uint32_t)(list - 1), (uint32_t)nodes, (uint32_t)(leaf - 1)};
+		bool overflow = false;
+		const int rc = attempt(d_tris, n, d_vertices, bbox_min, bbox_max, caps, out, &overflow, err, err_len);
+		if (rc) return rc;
+		if (!overflow) return 0;
+	}
+	say(err, err_len, "kd build: the tree of this mesh outgrows the build buffers (a degenerate mesh?)");
+	return HXR_E_INVALID;
+}
+
+}  // namespace hxr_kd

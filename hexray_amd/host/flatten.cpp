@@ -1,6 +1,9 @@
 // .hexray blocks -> flat element tables.  Each builder cites the reference fillProperties /
 // beginRender / beginFrame it reproduces.
 #include "flatten.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -210,8 +213,14 @@ struct Loader {
 			bool present;
 			std::string fn = resolve(b, "file", present);
 			if (!present) b.require("file");
+			const auto t0 = std::chrono::steady_clock::now();
 			if (!md.load_obj(fn)) throw ParseError(b.line_end, "Could not parse OBJ file!");
-			md.begin_render();
+			const auto t1 = std::chrono::steady_clock::now();
+			md.begin_render(!fs.gpu_kd_build);
+			if (getenv("HXH_TIMING"))   // developer aid: where the host preparation of a mesh goes
+				fprintf(stderr, "[hxh] %s: OBJ parse + prepareTriangles %.1f ms, kd build %.1f ms (%d triangles, %lld nodes, %zu leaf entries)\n", fn.c_str(),
+				        std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(),
+				        (int)md.triangles.size(), (long long)md.kd_nodes.size(), md.leaf_indices.size());
 			hxr_mesh m;
 			memset(&m, 0, sizeof m);
 			m.faceted = md.faceted;
@@ -528,7 +537,7 @@ void FlatScene::refresh_desc()
 #undef HXH_TABLE
 }
 
-std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables)
+std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build)
 {
 	std::ifstream in(scene_path);
 	if (!in) throw std::runtime_error("Cannot open scene file `" + scene_path + "'!");
@@ -539,6 +548,7 @@ std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::
 
 	auto fs = std::make_unique<FlatScene>();
 	fs->gpu_heightfield_tables = gpu_heightfield_tables;
+	fs->gpu_kd_build = gpu_kd_build;
 	// defaults, src/scene.h:244-269
 	set_color(fs->settings.ambient, 0.15f, 0.15f, 0.15f);
 	set_color(fs->settings.background, 0, 0, 0);

@@ -21,7 +21,9 @@ typedef struct hxh_scene hxh_scene;
 hxh_scene* hxh_scene_load(const char* scene_path, const char* overlay_text, char* err, size_t err_len);
 /* flags: HXH_GPU_HEIGHTFIELD_TABLES = leave Heightfield::maxH / highMap (src/heightfield.cpp:49-81,222-235) to the render module, which
  * builds them on the GPU (hxr_heightfield::first_maxh = first_highmap = -1).  A descriptor loaded this way is for the HIP module only. */
-enum { HXH_GPU_HEIGHTFIELD_TABLES = 1u };
+/*        HXH_GPU_KD_BUILD = skip Mesh::buildKD (src/mesh.cpp:95-122) on the host: meshes that want a tree say has_kd = 1 with num_kd_nodes = 0, and the
+ * device scene must be created with HXR_ACCEL_REFERENCE_DEVICE_BUILD (or HXR_ACCEL_SAH), which build it from the triangles. */
+enum { HXH_GPU_HEIGHTFIELD_TABLES = 1u, HXH_GPU_KD_BUILD = 2u };
 hxh_scene* hxh_scene_load_ex(const char* scene_path, const char* overlay_text, unsigned flags, char* err, size_t err_len);
 const hxr_scene_desc* hxh_scene_desc(const hxh_scene* s);
 void hxh_scene_free(hxh_scene* s);

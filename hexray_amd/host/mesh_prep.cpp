@@ -217,7 +217,7 @@ struct KdBuilder {
 };
 }  // namespace
 
-void MeshData::begin_render()
+void MeshData::begin_render(bool build_kd)
 {
 	if (recenter) {
 		V3 c;
@@ -236,7 +236,7 @@ void MeshData::begin_render()
 	leaf_indices.clear();
 	stats = KdStats();
 	g_build_box_tests = 0;
-	if (use_kd) {
+	if (use_kd && build_kd) {
 		std::vector<int> all(triangles.size());
 		for (size_t i = 0; i < all.size(); i++) all[i] = int(i);
 		kd_nodes.resize(1);

@@ -28,7 +28,7 @@ struct MeshData {
 	KdStats stats;
 
 	bool load_obj(const std::string& path);   // Mesh::loadFromOBJ + prepareTriangles
-	void begin_render();                      // Mesh::beginRender
+	void begin_render(bool build_kd = true);  // Mesh::beginRender; build_kd false: the tree is left to the render module (HXR_ACCEL_REFERENCE_DEVICE_BUILD)
 };
 
 }  // namespace hxh

@@ -323,6 +323,11 @@ enum hxr_accel {
 	HXR_ACCEL_SAH = 1         /* kd-trees rebuilt per mesh with the surface-area heuristic ("a better
 	                             tree proven <= 1e-4 against the reference-identical one"); same walk, same leaf rule, same
 	                             triangle test -- ties between triangles hit at bit-equal distance may resolve differently */
+	,
+	HXR_ACCEL_REFERENCE_DEVICE_BUILD = 2 /* the reference's tree again (midpoint splits, axis = depth % 3, leaves below 20 triangles or
+	                             past depth 64, BBox::intersectTriangle decides membership), but BUILT BY THE MODULE ON THE GPU from
+	                             the mesh's triangles at hxr_scene_create: the descriptor's kd_nodes / leaf_indices are not read
+	                             and may be absent (num_kd_nodes = 0 with has_kd = 1).  See hxr_kd_build_device. */
 };
 
 typedef struct hxr_scene_options {
@@ -347,6 +352,17 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* desc, const hxr_scene_optio
  * nodes == NULL to learn the sizes; returns 0 or a negative HXR_E_*. */
 int hxr_sah_build(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf_indices,
                   int64_t* num_nodes, int64_t* num_leaf_indices, int* max_depth);
+
+/* Mesh::buildKD (reference src/mesh.cpp:95-122) on the GPU: the tree HXR_ACCEL_REFERENCE_DEVICE_BUILD builds for mesh `mesh` of
+ * `desc`, returned in the descriptor's node format and in the numbering of a depth-first host build (a node's child pair is
+ * appended when the node is split, left subtree first; leaf lists in depth-first order), so that it can be compared with a
+ * host-built tree entry by entry or handed to other code.  Needs hxr_init; uploads the mesh's triangles and vertices itself.
+ * Call with nodes == NULL to learn the sizes.  *build_ms (optional): the build without the upload, copy back and renumbering.
+ * Arithmetic: IEEE FP64 with the device compiler's FMA contraction.  A host build compiled with other contraction / fast-math
+ * choices can classify a triangle that only grazes a split plane differently (the reference's own tree depends on its compiler
+ * flags in the same way); tests/test_gpu_kd_build.py compares the two builds for every mesh under data/geom. */
+int hxr_kd_build_device(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf_indices,
+                        int64_t* num_nodes, int64_t* num_leaf_indices, int* max_depth, double* build_ms);
 
 /* Nodes / leaf entries / depth of the tree actually walked for mesh `mesh` (after an HXR_ACCEL_SAH rebuild these
  * differ from the descriptor's).  The reference prints the same statistics at load (src/mesh.cpp:39-47). */

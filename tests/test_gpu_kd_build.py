@@ -1,0 +1,77 @@
+"""Mesh::buildKD as GPU kernels (hxr_kd_build_device / HXR_ACCEL_REFERENCE_DEVICE_BUILD).
+
+The device build must produce the tree the host builder produces -- same splits, same leaf lists in the same order -- for every
+mesh the reference ships, and a scene created from a descriptor WITHOUT trees must render exactly what the scene with the
+host-built trees renders."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+from desc_types import SceneDesc
+
+pytestmark = pytest.mark.gpu
+ALL_MESHES = os.path.join(ROOT, "tests", "golden", "all_meshes.hexray")
+
+
+def host_tree(desc, mi):
+    import hexray_amd as hx
+    m = desc.meshes[mi]
+    nodes = np.zeros(m.num_kd_nodes, dtype=hx.KD_NODE_DTYPE)
+    if m.num_kd_nodes:
+        ctypes.memmove(nodes.ctypes.data, ctypes.addressof(desc.kd_nodes[m.first_kd_node]), nodes.nbytes)
+    leaf = np.array([desc.leaf_indices[m.first_leaf_index + i] for i in range(m.num_leaf_indices)], dtype=np.int32)
+    return nodes, leaf
+
+
+def test_device_kd_build_equals_host_build_for_every_reference_mesh(gpu):
+    hx = gpu
+    hs = hx.HostScene(ALL_MESHES)
+    desc = SceneDesc.from_address(hs.desc)
+    assert desc.num_meshes == 9
+    for mi in range(desc.num_meshes):
+        want_nodes, want_leaf = host_tree(desc, mi)
+        nodes, leaf, depth, ms = hx.kd_build_device(hs, mi)
+        assert len(nodes) == len(want_nodes) and len(leaf) == len(want_leaf), (mi, len(nodes), len(want_nodes), len(leaf), len(want_leaf))
+        for field in ("axis", "first", "count", "parent"):
+            assert np.array_equal(nodes[field], want_nodes[field]), (mi, field)
+        assert np.array_equal(nodes["split"].view(np.uint64), want_nodes["split"].view(np.uint64)), mi   # bit-exact split positions
+        assert np.array_equal(leaf, want_leaf), mi
+        assert depth == hs.kd_stats()[mi][2]
+
+
+def test_scene_without_trees_renders_what_the_host_built_trees_render(gpu):
+    hx = gpu
+    ov = hx.overlay_text(width=480, height=270, dof=True, num_samples=4)
+    with_trees = hx.HostScene(scene_path("meshes.hexray"), ov)
+    without = hx.HostScene(scene_path("meshes.hexray"), ov, gpu_kd_build=True)
+    d = SceneDesc.from_address(without.desc)
+    assert d.num_kd_nodes == 0 and d.num_leaf_indices == 0 and all(d.meshes[i].has_kd for i in range(d.num_meshes))
+    p = hx.frame_params(collect_counters=True)
+    a = hx.DeviceScene(with_trees)
+    want = a.render(p)
+    want_counters = a.counters()
+    b = hx.DeviceScene(without, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD)
+    got = b.render(p)
+    assert np.array_equal(got, want)
+    assert b.counters() == want_counters
+    for mi in range(d.num_meshes):
+        assert b.tree_stats(mi) == a.tree_stats(mi)
+    # the SAH rebuild reads triangles only, so it accepts the tree-less descriptor as well
+    c = hx.DeviceScene(without, accel=hx.ACCEL_SAH)
+    rms = np.sqrt(np.mean((c.render(p).astype(np.float64) - want) ** 2, axis=(0, 1)))
+    assert rms.max() <= 1e-4, rms
+
+
+def test_device_kd_build_argument_checks(gpu):
+    hx = gpu
+    hs = hx.HostScene(ALL_MESHES)
+    lib = hx.hip_lib()
+    assert lib.hxr_kd_build_device(hs.desc, 99, None, 0, None, 0, None, None, None, None) < 0
+    n, l = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.hxr_kd_build_device(hs.desc, 2, None, 0, None, 0, ctypes.byref(n), ctypes.byref(l), None, None) == 0 and n.value > 1
+    small = np.zeros(1, dtype=hx.KD_NODE_DTYPE)
+    leaves = np.zeros(1, dtype=np.int32)
+    assert lib.hxr_kd_build_device(hs.desc, 2, small.ctypes.data, 1, leaves.ctypes.data, 1, None, None, None, None) < 0
