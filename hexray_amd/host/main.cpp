@@ -19,7 +19,7 @@ static void usage()
 {
 	printf("usage: hexray [scene.hexray] [--width W] [--height H] [--aa on|off] [--dof on|off] [--spp N]\n"
 	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc|prepass] [--seed S] [--device D]\n"
-	       "              [--frames N] [--out frame.bmp|frame.exr|frame.raw] [--counters] [--accel reference|sah]\n"
+	       "              [--frames N] [--out frame.bmp|frame.exr|frame.raw] [--counters] [--accel reference|sah|device-build]\n"
 	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n"
 	       "              [--interactive FRAMES] [--fovea RADIUS]\n");
 }
@@ -56,7 +56,7 @@ int main(int argc, char** argv)
 		else if (a == "--frames") frames = atoi(next());
 		else if (a == "--out") out = next();
 		else if (a == "--counters") fp.collect_counters = 1;
-		else if (a == "--accel") { std::string v = next(); opt.accel = v == "sah" ? HXR_ACCEL_SAH : HXR_ACCEL_REFERENCE; }
+		else if (a == "--accel") { std::string v = next(); opt.accel = v == "sah" ? HXR_ACCEL_SAH : v == "device-build" ? HXR_ACCEL_REFERENCE_DEVICE_BUILD : HXR_ACCEL_REFERENCE; }
 		else if (a == "--no-adaptive-schedule") opt.no_adaptive_schedule = 1;
 		else if (a == "--deferred-rays") opt.deferred_rays = 1;
 		else if (a == "--gpus") { int n = atoi(next()); devices.clear(); for (int k = 0; k < n; k++) devices.push_back(k); }
@@ -74,7 +74,9 @@ int main(int argc, char** argv)
 	if (fp.mode != HXR_MODE_MONTE_CARLO && fp.mode != HXR_MODE_PREPASS) fp.spp = 0;
 
 	char err[1024] = "";
-	hxh_scene* hs = hxh_scene_load_ex(scene.c_str(), overlay.c_str(), HXH_GPU_HEIGHTFIELD_TABLES, err, sizeof err);   // the module builds the maxima tables on the GPU
+	// the module builds the heightfield maxima tables on the GPU, and with --accel device-build the kd-trees (Mesh::buildKD) as well
+	const unsigned load_flags = HXH_GPU_HEIGHTFIELD_TABLES | (opt.accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD ? HXH_GPU_KD_BUILD : 0u);
+	hxh_scene* hs = hxh_scene_load_ex(scene.c_str(), overlay.c_str(), load_flags, err, sizeof err);
 	if (!hs) {
 		printf("Could not parse the scene file (%s)!\n%s\n", scene.c_str(), err);
 		return 1;
@@ -137,6 +139,14 @@ int main(int argc, char** argv)
 		if (hxr_init(device)) { printf("GPU init failed: %s\n", hxr_last_error()); return 1; }
 		ds = hxr_scene_create_ex(d, &opt);
 		if (!ds) { printf("hxr_scene_create_ex failed: %s\n", hxr_last_error()); return 1; }
+		if (opt.accel != HXR_ACCEL_REFERENCE)   // the trees were (re)built by the module: its statistics instead of the loader's
+			for (int m = 0; m < (int)d->num_meshes; m++) {
+				int64_t nodes = 0, entries = 0;
+				int depth = 0;
+				if (!hxr_scene_tree_stats(ds, m, &nodes, &entries, &depth) && nodes)
+					printf("K-d Tree statistics (%s):\n   nodes            : %lld\n   leaf entries     : %lld\n   max depth        : %d\n",
+					       opt.accel == HXR_ACCEL_SAH ? "SAH rebuild" : "built on the GPU", (long long)nodes, (long long)entries, depth);
+			}
 		for (int f = 0; f < frames && rc == 0; f++) rc = hxr_render(ds, &fp, vfb.data(), (size_t)W * 12, nullptr, progress ? +on_tile : nullptr, &tiles_reported);
 	}
 	auto t1 = std::chrono::steady_clock::now();

@@ -236,3 +236,17 @@ def test_exr_writer_round_trip(tmp_path):
     for v in (0.0, 1.0, -2.5, 1e-7, 6.1e-5, 65504.0, 65520.0, 2049.0, 2051.0, 0.1):
         assert lib.hxh_float_to_half(ctypes.c_float(v)) == int(np.float32(v).astype(np.float16).view(np.uint16)), v
     assert open(path, "rb").read(4) == bytes([0x76, 0x2f, 0x31, 0x01])
+
+
+def test_loader_can_leave_the_kd_trees_to_the_render_module():
+    """HXH_GPU_KD_BUILD: meshes keep has_kd but carry no nodes / leaf lists; everything else of the descriptor is unchanged."""
+    import hexray_amd as hx
+    from desc_types import SceneDesc
+    full = hx.HostScene(scene_path("meshes.hexray"))
+    bare = hx.HostScene(scene_path("meshes.hexray"), gpu_kd_build=True)
+    a, b = SceneDesc.from_address(full.desc), SceneDesc.from_address(bare.desc)
+    assert a.num_kd_nodes > 0 and b.num_kd_nodes == 0 and b.num_leaf_indices == 0
+    assert a.num_meshes == b.num_meshes and a.num_triangles == b.num_triangles and a.f64_pool_size == b.f64_pool_size
+    for i in range(a.num_meshes):
+        assert b.meshes[i].has_kd == a.meshes[i].has_kd and b.meshes[i].num_kd_nodes == 0
+        assert list(b.meshes[i].bbox_min) == list(a.meshes[i].bbox_min) and list(b.meshes[i].bbox_max) == list(a.meshes[i].bbox_max)
