@@ -184,6 +184,37 @@ int validate(const hxr_scene_desc* d)
 			}
 		}
 	}
+	// meshes: every index a kernel will follow (vertex / normal / uv numbers of the triangles, kd children, leaf lists) stays inside its table
+	if (d->num_meshes < 0 || d->num_triangles < 0 || d->num_kd_nodes < 0 || d->num_leaf_indices < 0 || d->f64_pool_size < 0 || d->f32_pool_size < 0) { set_err("negative table size"); return HXR_E_INVALID; }
+	for (int64_t i = 0; i < d->num_meshes; i++) {
+		const hxr_mesh& m = d->meshes[i];
+		auto vectors_ok = [&](int64_t first, int64_t n) { return first >= 0 && n >= 0 && first <= d->f64_pool_size / 3 && n <= d->f64_pool_size / 3 - first; };
+		auto range_ok = [](int64_t first, int64_t n, int64_t table) { return first >= 0 && n >= 0 && first <= table && n <= table - first; };
+		if (!vectors_ok(m.first_vertex, m.num_vertices) || !vectors_ok(m.first_normal, m.num_normals) || !vectors_ok(m.first_uv, m.num_uvs) ||
+		    !range_ok(m.first_triangle, m.num_triangles, d->num_triangles) || !range_ok(m.first_kd_node, m.num_kd_nodes, d->num_kd_nodes) ||
+		    !range_ok(m.first_leaf_index, m.num_leaf_indices, d->num_leaf_indices) || m.num_triangles > INT32_MAX || m.num_kd_nodes > INT32_MAX) {
+			set_err("mesh %lld: a table range lies outside the descriptor", (long long)i);
+			return HXR_E_INVALID;
+		}
+		for (int64_t k = 0; k < m.num_triangles; k++) {
+			const hxr_triangle& t = d->triangles[m.first_triangle + k];
+			for (int c = 0; c < 3; c++)
+				if (t.v[c] < 0 || t.v[c] >= m.num_vertices || t.n[c] < 0 || (!m.faceted && t.n[c] >= m.num_normals) || t.t[c] < 0 || t.t[c] >= m.num_uvs) {
+					set_err("mesh %lld: triangle %lld refers outside the vertex / normal / uv arrays", (long long)i, (long long)k);
+					return HXR_E_INVALID;
+				}
+		}
+		for (int64_t k = 0; k < m.num_kd_nodes; k++) {   // children are stored after their parent (every builder here numbers them so): no cycles
+			const hxr_kd_node& n = d->kd_nodes[m.first_kd_node + k];
+			const bool ok = n.axis == 3 ? (n.first >= 0 && n.count >= 0 && (int64_t)n.first + n.count <= m.num_leaf_indices)
+			                            : (n.axis >= 0 && n.axis <= 2 && n.first > k && (int64_t)n.first + 1 < m.num_kd_nodes);
+			if (!ok) { set_err("mesh %lld: kd node %lld is malformed", (long long)i, (long long)k); return HXR_E_INVALID; }
+		}
+		for (int64_t k = 0; k < m.num_leaf_indices; k++) {
+			const int32_t t = d->leaf_indices[m.first_leaf_index + k];
+			if (t < 0 || t >= m.num_triangles) { set_err("mesh %lld: leaf entry %lld names triangle %d of %lld", (long long)i, (long long)k, t, (long long)m.num_triangles); return HXR_E_INVALID; }
+		}
+	}
 	for (int64_t i = 0; i < d->num_nodes; i++) {
 		const hxr_node& n = d->nodes[i];
 		if (n.geometry < 0 || n.geometry >= d->num_geometries || n.shader < 0 || n.shader >= d->num_shaders || n.bump >= d->num_textures) {

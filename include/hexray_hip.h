@@ -78,7 +78,8 @@ typedef struct hxr_triangle {
 	double dNdx[3], dNdy[3];
 } hxr_triangle;
 
-/* KDTreeNode (reference src/mesh.h:32-60) flattened: children are stored as an adjacent pair. */
+/* KDTreeNode (reference src/mesh.h:32-60) flattened: children are stored as an adjacent pair, AFTER their parent (first > the node's own
+ * index: what a depth-first builder that appends a pair when it splits a node produces; hxr_scene_create refuses anything else). */
 typedef struct hxr_kd_node {
 	int32_t axis;      /* 0,1,2 = split axis of a binary node; 3 = leaf (AXIS_NONE) */
 	int32_t first;     /* binary: index of the LEFT child (right = first+1), local to the mesh;

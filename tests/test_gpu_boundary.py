@@ -137,3 +137,45 @@ def test_scene_tables_prepared_on_the_gpu(gpu):
     p = hx.frame_params(mode=hx.MODE_ADAPTIVE_AA)
     assert np.array_equal(a.render(p), b.render(p))
     a.close(); b.close()
+
+
+def test_malformed_mesh_tables_are_refused_before_any_kernel_sees_them(gpu):
+    """A descriptor whose mesh indices point outside their tables must come back as HXR_E_INVALID from hxr_scene_create: the kernels
+    follow these indices without checks (a stray one is a GPU fault, not an exception)."""
+    hx = gpu
+    from desc_types import desc_of
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(width=64, height=48))
+    d = desc_of(hs)
+    lib = hx.hip_lib()
+
+    def refused(what):
+        s = lib.hxr_scene_create(hs.desc)
+        if s:
+            lib.hxr_scene_destroy(s)
+        assert not s, what
+        assert what in lib.hxr_last_error().decode(), (what, lib.hxr_last_error())
+
+    m = d.meshes[1]
+    node = d.kd_nodes[m.first_kd_node]                     # the root: a binary node
+    keep = node.first
+    node.first = 0                                         # a child that is its own ancestor
+    refused("kd node 0 is malformed")
+    node.first = int(m.num_kd_nodes)                       # children past the end
+    refused("kd node 0 is malformed")
+    node.first = keep
+    keep = d.leaf_indices[m.first_leaf_index]
+    d.leaf_indices[m.first_leaf_index] = int(m.num_triangles)
+    refused("leaf entry 0 names triangle")
+    d.leaf_indices[m.first_leaf_index] = keep
+    tri = d.triangles[m.first_triangle + 5]
+    keep = tri.v[1]
+    tri.v[1] = int(m.num_vertices)
+    refused("triangle 5 refers outside")
+    tri.v[1] = keep
+    keep = m.num_leaf_indices
+    m.num_leaf_indices = int(d.num_leaf_indices) + 1
+    refused("a table range lies outside the descriptor")
+    m.num_leaf_indices = keep
+    s = lib.hxr_scene_create(hs.desc)                      # restored: accepted again
+    assert s
+    lib.hxr_scene_destroy(s)
