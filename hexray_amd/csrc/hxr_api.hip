@@ -215,6 +215,29 @@ int validate(const hxr_scene_desc* d)
 			if (t < 0 || t >= m.num_triangles) { set_err("mesh %lld: leaf entry %lld names triangle %d of %lld", (long long)i, (long long)k, t, (long long)m.num_triangles); return HXR_E_INVALID; }
 		}
 	}
+	if (d->num_heightfields < 0) { set_err("negative table size"); return HXR_E_INVALID; }
+	for (int64_t i = 0; i < d->num_heightfields; i++) {
+		const hxr_heightfield& h = d->heightfields[i];
+		const int64_t cells = (int64_t)h.W * h.H;
+		auto floats_ok = [&](int64_t first, int64_t n) { return first >= 0 && first <= d->f32_pool_size && n <= d->f32_pool_size - first; };
+		const bool tables = h.first_maxh >= 0 && h.first_highmap >= 0;
+		if (h.W <= 0 || h.H <= 0 || cells > (1ll << 30) || !floats_ok(h.first_height, cells) || (tables && (!floats_ok(h.first_maxh, cells) || !floats_ok(h.first_highmap, cells * 16))) ||
+		    h.max_k < 0 || h.max_k > 16 || h.first_normal < 0 || h.first_normal > d->f64_pool_size / 3 || cells > d->f64_pool_size / 3 - h.first_normal) {
+			set_err("heightfield %lld: a table range lies outside the descriptor", (long long)i);
+			return HXR_E_INVALID;
+		}
+	}
+	for (int64_t i = 0; i < d->num_bitmaps; i++) {
+		const hxr_bitmap& b = d->bitmaps[i];
+		const int64_t floats = (int64_t)b.width * b.height * 3;
+		if (b.width < 0 || b.height < 0 || b.first_texel < 0 || b.first_texel > d->f32_pool_size || floats > d->f32_pool_size - b.first_texel) {
+			set_err("bitmap %lld: texels outside the descriptor", (long long)i);
+			return HXR_E_INVALID;
+		}
+	}
+	if (d->environment.present && d->environment.loaded)
+		for (int side = 0; side < 6; side++)
+			if (d->environment.side_bitmap[side] < 0 || d->environment.side_bitmap[side] >= d->num_bitmaps) { set_err("environment side %d: bad bitmap reference", side); return HXR_E_INVALID; }
 	for (int64_t i = 0; i < d->num_nodes; i++) {
 		const hxr_node& n = d->nodes[i];
 		if (n.geometry < 0 || n.geometry >= d->num_geometries || n.shader < 0 || n.shader >= d->num_shaders || n.bump >= d->num_textures) {

@@ -179,3 +179,40 @@ def test_malformed_mesh_tables_are_refused_before_any_kernel_sees_them(gpu):
     s = lib.hxr_scene_create(hs.desc)                      # restored: accepted again
     assert s
     lib.hxr_scene_destroy(s)
+
+
+def test_malformed_heightfield_and_bitmap_ranges_are_refused(gpu):
+    hx = gpu
+    from desc_types import desc_of
+    hs = hx.HostScene(scene_path("heightfield.hexray"), hx.overlay_text(width=64, height=48))
+    d = desc_of(hs)
+    lib = hx.hip_lib()
+
+    def refused(what):
+        s = lib.hxr_scene_create(hs.desc)
+        if s:
+            lib.hxr_scene_destroy(s)
+        assert not s, what
+        assert what in lib.hxr_last_error().decode(), (what, lib.hxr_last_error())
+
+    h = d.heightfields[0]
+    keep = h.first_highmap
+    h.first_highmap = int(d.f32_pool_size) - 100           # the 16-level pyramid would run off the pool
+    refused("heightfield 0: a table range lies outside")
+    h.first_highmap = keep
+    keep = h.max_k
+    h.max_k = 17
+    refused("heightfield 0: a table range lies outside")
+    h.max_k = keep
+    b = d.bitmaps[0]
+    keep = b.first_texel
+    b.first_texel = int(d.f32_pool_size) - 1
+    refused("bitmap 0: texels outside")
+    b.first_texel = keep
+    keep = d.environment.side_bitmap[3]
+    d.environment.side_bitmap[3] = int(d.num_bitmaps)
+    refused("environment side 3")
+    d.environment.side_bitmap[3] = keep
+    s = lib.hxr_scene_create(hs.desc)
+    assert s
+    lib.hxr_scene_destroy(s)
