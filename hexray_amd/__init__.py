@@ -51,7 +51,8 @@ ACCEL_REFERENCE, ACCEL_SAH, ACCEL_REFERENCE_DEVICE_BUILD = 0, 1, 2
 class SceneOptions(ctypes.Structure):
     """hxr_scene_options (include/hexray_hip.h)."""
 
-    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32), ("no_adaptive_schedule", ctypes.c_int32), ("deferred_rays", ctypes.c_int32)]
+    _fields_ = [("struct_size", ctypes.c_uint32), ("accel", ctypes.c_int32), ("no_adaptive_schedule", ctypes.c_int32), ("deferred_rays", ctypes.c_int32),
+                ("device_prepare_triangles", ctypes.c_int32)]
 
 
 class FrameTiming(ctypes.Structure):
@@ -132,13 +133,16 @@ class HostScene:
     (reference src/scene.cpp:764-778, src/camera.h:57-72), so overrides are expressed the same way.
     """
 
-    def __init__(self, path: str, overlay: str = "", gpu_heightfield_tables: bool = False, gpu_kd_build: bool = False):
+    def __init__(self, path: str, overlay: str = "", gpu_heightfield_tables: bool = False, gpu_kd_build: bool = False,
+                 gpu_prepare_triangles: bool = False):
         """``gpu_heightfield_tables``: leave the heightfield maxima tables to the render module (it builds them on the GPU); such a
         scene is for the HIP module only -- the CPU oracle needs the host's tables.
-        ``gpu_kd_build``: skip Mesh::buildKD on the host; create the DeviceScene with ACCEL_REFERENCE_DEVICE_BUILD (or ACCEL_SAH)."""
+        ``gpu_kd_build``: skip Mesh::buildKD on the host; create the DeviceScene with ACCEL_REFERENCE_DEVICE_BUILD (or ACCEL_SAH).
+        ``gpu_prepare_triangles``: skip Mesh::prepareTriangles; create the DeviceScene with ``device_prepare_triangles=True``."""
         lib = host_lib()
         err = ctypes.create_string_buffer(1024)
-        self._h = lib.hxh_scene_load_ex(os.fsencode(path), overlay.encode(), (1 if gpu_heightfield_tables else 0) | (2 if gpu_kd_build else 0), err, len(err))
+        self._h = lib.hxh_scene_load_ex(os.fsencode(path), overlay.encode(), (1 if gpu_heightfield_tables else 0) | (2 if gpu_kd_build else 0) | (4 if gpu_prepare_triangles else 0),
+                                        err, len(err))
         if not self._h:
             raise ValueError(f"cannot load scene {path}: {err.value.decode(errors='replace')}")
         self.path = path
@@ -349,13 +353,15 @@ class DeviceScene:
     """A scene resident in HBM (hxr_scene).  ``accel``: ACCEL_REFERENCE walks the kd-trees of the descriptor (the
     reference's own), ACCEL_SAH rebuilds them with the surface-area heuristic (hxr_scene_create_ex)."""
 
-    def __init__(self, host_scene: HostScene, accel: int = 0, adaptive_schedule: bool = True, deferred_rays: bool = False):
+    def __init__(self, host_scene: HostScene, accel: int = 0, adaptive_schedule: bool = True, deferred_rays: bool = False,
+                 device_prepare_triangles: bool = False):
+        """``device_prepare_triangles``: Mesh::prepareTriangles runs on the GPU (the descriptor's derived triangle fields are not read)."""
         if _initialised_device is None:
             init(0)
-        if accel == ACCEL_REFERENCE and adaptive_schedule and not deferred_rays:
+        if accel == ACCEL_REFERENCE and adaptive_schedule and not deferred_rays and not device_prepare_triangles:
             self._s = hip_lib().hxr_scene_create(host_scene.desc)
         else:
-            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel, 0 if adaptive_schedule else 1, 1 if deferred_rays else 0)
+            opt = SceneOptions(ctypes.sizeof(SceneOptions), accel, 0 if adaptive_schedule else 1, 1 if deferred_rays else 0, 1 if device_prepare_triangles else 0)
             self._s = hip_lib().hxr_scene_create_ex(host_scene.desc, ctypes.byref(opt))
         if not self._s:
             raise HipError("hxr_scene_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))

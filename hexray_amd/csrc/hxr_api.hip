@@ -89,6 +89,7 @@ struct hxr_scene {
 	struct TreeStats { int64_t nodes, leaf_entries; int depth; };
 	std::vector<TreeStats> tree_stats;   // per mesh: the tree actually walked
 	double kd_build_ms = 0;              // HXR_ACCEL_REFERENCE_DEVICE_BUILD: time of the kd builds on the GPU, all meshes
+	const hxr_triangle* d_triangles = nullptr;   // the triangle records in HBM (hxr_scene_verify_tables reads them back)
 	// per-frame scratch, grown on demand
 	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
 	float* d_scratch = nullptr;     size_t scratch_bytes = 0;  // sharded-AA full frame
@@ -940,8 +941,12 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (g_device < 0) { set_err("hxr_init has not been called"); return nullptr; }
 	if (validate(d)) return nullptr;
 	int accel = HXR_ACCEL_REFERENCE;
+	hxr_scene_options own;   // the caller's record may be an older, shorter one: fields it does not have are 0
+	memset(&own, 0, sizeof own);
 	if (opt) {
-		if (opt->struct_size < sizeof(hxr_scene_options)) { set_err("hxr_scene_options.struct_size too small"); return nullptr; }
+		if (opt->struct_size < 2 * sizeof(uint32_t)) { set_err("hxr_scene_options.struct_size too small"); return nullptr; }
+		memcpy(&own, opt, std::min<size_t>(opt->struct_size, sizeof own));
+		opt = &own;
 		accel = opt->accel;
 		if (accel != HXR_ACCEL_REFERENCE && accel != HXR_ACCEL_SAH && accel != HXR_ACCEL_REFERENCE_DEVICE_BUILD) { set_err("unknown acceleration structure %d", accel); return nullptr; }
 	}
@@ -973,6 +978,16 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (s->arena.upload(d->f64_pool, (size_t)d->f64_pool_size, &d_f64)) return fail();
 	if (s->arena.upload(d->f32_pool, (size_t)d->f32_pool_size, &d_f32)) return fail();
 	if (s->arena.upload(d->triangles, (size_t)d->num_triangles, &d_tris)) return fail();
+
+	if (own.device_prepare_triangles)   // Mesh::prepareTriangles as a kernel over the records just uploaded (before anything reads AB / AC / ABcrossAC)
+		for (int64_t i = 0; i < d->num_meshes; i++) {
+			const hxr_mesh& m = d->meshes[i];
+			if (hxr_kd::prepare_triangles(const_cast<hxr_triangle*>(d_tris) + m.first_triangle, m.num_triangles, d_f64 + m.first_vertex * 3, d_f64 + m.first_uv * 3)) {
+				set_err("prepare_triangles kernel failed to launch");
+				return fail();
+			}
+		}
+	s->d_triangles = d_tris;
 
 	std::vector<HxrMeshDev> meshes((size_t)d->num_meshes);
 	std::vector<HxrKdSlim> all_kd;
@@ -1613,6 +1628,27 @@ int hxr_scene_verify_tables(const hxr_scene* s, const hxr_scene_desc* d, int64_t
 			for (int c = 0; c < 3; c++) { w.A[c] = verts[(size_t)t.v[0] * 3 + c]; w.AB[c] = t.AB[c]; w.AC[c] = t.AC[c]; w.N[c] = t.ABcrossAC[c]; }
 			if (memcmp(&w, &hot[(size_t)k], sizeof w) != 0) ++*mismatches;
 		}
+	}
+	// the derived fields of the triangle records (computed on the GPU with device_prepare_triangles, copies of the descriptor's otherwise)
+	if (d->num_triangles > 0 && s->d_triangles) {
+		std::vector<hxr_triangle> got((size_t)d->num_triangles);
+		HIP_TRY(hipMemcpy(got.data(), s->d_triangles, got.size() * sizeof(hxr_triangle), hipMemcpyDeviceToHost));
+		auto same = [](const double* a, const double* b) {   // bit-equal, or both NaN (degenerate uv triangles: 0/0 on both sides)
+			for (int c = 0; c < 3; c++)
+				if (memcmp(a + c, b + c, sizeof(double)) != 0 && !(a[c] != a[c] && b[c] != b[c])) return false;
+			return true;
+		};
+		int64_t per_field[6] = {0, 0, 0, 0, 0, 0};
+		for (int64_t k = 0; k < d->num_triangles; k++) {
+			const hxr_triangle &a = got[(size_t)k], &b = d->triangles[k];
+			const bool ok[6] = {same(a.gnormal, b.gnormal), same(a.AB, b.AB), same(a.AC, b.AC), same(a.ABcrossAC, b.ABcrossAC), same(a.dNdx, b.dNdx), same(a.dNdy, b.dNdy)};
+			bool all = true;
+			for (int f = 0; f < 6; f++) { if (!ok[f]) per_field[f]++; all = all && ok[f]; }
+			if (!all) ++*mismatches;
+		}
+		if (getenv("HXR_VERIFY_VERBOSE"))   // developer aid: which derived field disagrees
+			fprintf(stderr, "[hxr] triangle records differing in gnormal %lld, AB %lld, AC %lld, ABcrossAC %lld, dNdx %lld, dNdy %lld (of %lld)\n", (long long)per_field[0],
+			        (long long)per_field[1], (long long)per_field[2], (long long)per_field[3], (long long)per_field[4], (long long)per_field[5], (long long)d->num_triangles);
 	}
 	// heightfield maxima tables against the descriptor's own (when it carries them)
 	std::vector<HxrHeightfieldDev> hfs((size_t)d->num_heightfields);

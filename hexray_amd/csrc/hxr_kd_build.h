@@ -1,4 +1,4 @@
-// Mesh::buildKD on the GPU ("scene preparation on the fast path").
+// Mesh preparation on the GPU ("scene preparation on the fast path"): Mesh::buildKD and Mesh::prepareTriangles.
 //
 // Builds the REFERENCE's kd-tree of one mesh -- midpoint split on axis depth % 3, a node becomes a leaf below 20
 // triangles or past depth 64, a triangle goes to every child whose box BBox::intersectTriangle says it touches
@@ -26,5 +26,9 @@ struct DeviceBuiltTree {
 // Returns 0 or a negative HXR_E_*; `err` receives a message on failure.
 int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
                          DeviceBuiltTree& out, char* err, size_t err_len);
+
+// Mesh::prepareTriangles (src/mesh.cpp:370-396) on the GPU: gnormal, AB, AC, ABcrossAC, dNdx, dNdy of `num_triangles` records are
+// (re)computed in place from the vertex and uv numbers they carry.  Asynchronous on the null stream; returns 0 or HXR_E_HIP.
+int prepare_triangles(hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double* d_uvs);
 
 }  // namespace hxr_kd

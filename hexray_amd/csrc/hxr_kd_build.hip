@@ -231,6 +231,52 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* 
 	}
 }
 
+// Mesh::prepareTriangles (src/mesh.cpp:370-396): the derived fields of every triangle record, one triangle per lane, written in place.
+//
+// The records must come out bit for bit as the host loader's (hexray_amd/host/mesh_prep.cpp), which is compiled with the reference's
+// Release flags (-O3 -ffast-math -march=haswell): every sum of products below is therefore written as the chain of fused multiply-adds
+// that build executes (read off its code; tests/test_gpu_kd_build.py holds the two sides together), with contraction switched off so
+// that nothing else fuses.  What -ffast-math contributes beyond fusing: Vector::normalize multiplies by ONE reciprocal of the length,
+// and the two 2x2 solves of dNdx / dNdy (src/mesh.cpp:360-368) share one reciprocal of their determinant.
+__global__ void prepare_triangles_kernel(hxr_triangle* __restrict__ tris, int64_t n, const double* __restrict__ verts, const double* __restrict__ uvs)
+{
+#pragma clang fp contract(off)
+	for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		hxr_triangle& t = tris[i];
+		double A[3], B[3], C[3], ta[2], tb[2], tc[2];
+		for (int k = 0; k < 3; k++) {
+			A[k] = verts[3 * (size_t)t.v[0] + k];
+			B[k] = verts[3 * (size_t)t.v[1] + k];
+			C[k] = verts[3 * (size_t)t.v[2] + k];
+		}
+		for (int k = 0; k < 2; k++) {
+			ta[k] = uvs[3 * (size_t)t.t[0] + k];
+			tb[k] = uvs[3 * (size_t)t.t[1] + k];
+			tc[k] = uvs[3 * (size_t)t.t[2] + k];
+		}
+		const double AB[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, AC[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+		// AB x AC: the subtrahend is rounded, the minuend fused
+		const double N[3] = {fma(AB[1], AC[2], -(AB[2] * AC[1])), fma(AB[2], AC[0], -(AB[0] * AC[2])), fma(AB[0], AC[1], -(AB[1] * AC[0]))};
+		const double kn = 1.0 / sqrt(fma(N[2], N[2], fma(N[0], N[0], N[1] * N[1])));
+		// px*tAB + qx*tAC = (1, 0), py*tAB + qy*tAC = (0, 1) by Cramer's rule
+		const double tABx = tb[0] - ta[0], tABy = tb[1] - ta[1], tACx = tc[0] - ta[0], tACy = tc[1] - ta[1];
+		const double inv = 1.0 / fma(tABx, tACy, -(tABy * tACx));
+		const double px = tACy * inv, qx = (ta[1] - tb[1]) * inv, py = (ta[0] - tc[0]) * inv, qy = tABx * inv;   // the negated differences are taken anew (a zero keeps its sign)
+		const double dx[3] = {fma(qx, AC[0], px * AB[0]), fma(qx, AC[1], px * AB[1]), fma(qx, AC[2], px * AB[2])};
+		const double dy[3] = {fma(qy, AC[0], py * AB[0]), fma(py, AB[1], qy * AC[1]), fma(py, AB[2], qy * AC[2])};
+		const double kx = 1.0 / sqrt(fma(dx[2], dx[2], fma(dx[0], dx[0], dx[1] * dx[1])));
+		const double ky = 1.0 / sqrt(fma(dy[0], dy[0], fma(dy[1], dy[1], dy[2] * dy[2])));
+		for (int k = 0; k < 3; k++) {
+			t.AB[k] = AB[k];
+			t.AC[k] = AC[k];
+			t.ABcrossAC[k] = N[k];
+			t.gnormal[k] = N[k] * kn;
+			t.dNdx[k] = dx[k] * kx;
+			t.dNdy[k] = dy[k] * ky;
+		}
+	}
+}
+
 void say(char* err, size_t n, const char* fmt, ...)
 {
 	if (!err || !n) return;
@@ -355,6 +401,14 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 }
 
 }  // namespace
+
+int prepare_triangles(hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double* d_uvs)
+{
+	if (num_triangles <= 0) return 0;
+	const int grid = (int)std::min<int64_t>((num_triangles + 255) / 256, 4096);
+	hipLaunchKernelGGL(prepare_triangles_kernel, dim3(grid), dim3(256), 0, nullptr, d_tris, num_triangles, d_vertices, d_uvs);
+	return hipGetLastError() == hipSuccess ? 0 : HXR_E_HIP;
+}
 
 int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
                          DeviceBuiltTree& out, char* err, size_t err_len)

@@ -213,6 +213,7 @@ struct Loader {
 			bool present;
 			std::string fn = resolve(b, "file", present);
 			if (!present) b.require("file");
+			md.defer_triangle_prep = fs.gpu_prepare_triangles;
 			const auto t0 = std::chrono::steady_clock::now();
 			if (!md.load_obj(fn)) throw ParseError(b.line_end, "Could not parse OBJ file!");
 			const auto t1 = std::chrono::steady_clock::now();
@@ -537,7 +538,7 @@ void FlatScene::refresh_desc()
 #undef HXH_TABLE
 }
 
-std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build)
+std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build, bool gpu_prepare_triangles)
 {
 	std::ifstream in(scene_path);
 	if (!in) throw std::runtime_error("Cannot open scene file `" + scene_path + "'!");
@@ -549,6 +550,7 @@ std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::
 	auto fs = std::make_unique<FlatScene>();
 	fs->gpu_heightfield_tables = gpu_heightfield_tables;
 	fs->gpu_kd_build = gpu_kd_build;
+	fs->gpu_prepare_triangles = gpu_prepare_triangles;
 	// defaults, src/scene.h:244-269
 	set_color(fs->settings.ambient, 0.15f, 0.15f, 0.15f);
 	set_color(fs->settings.background, 0, 0, 0);

@@ -25,7 +25,8 @@ hxh_scene* hxh_scene_load(const char* scene_path, const char* overlay_text, char
 hxh_scene* hxh_scene_load_ex(const char* scene_path, const char* overlay_text, unsigned flags, char* err, size_t err_len)
 {
 	try {
-		auto fs = hxh::load_scene(scene_path ? scene_path : "", overlay_text ? overlay_text : "", (flags & HXH_GPU_HEIGHTFIELD_TABLES) != 0, (flags & HXH_GPU_KD_BUILD) != 0);
+		auto fs = hxh::load_scene(scene_path ? scene_path : "", overlay_text ? overlay_text : "", (flags & HXH_GPU_HEIGHTFIELD_TABLES) != 0, (flags & HXH_GPU_KD_BUILD) != 0,
+		                          (flags & HXH_GPU_PREPARE_TRIANGLES) != 0);
 		hxh_scene* s = new hxh_scene;
 		s->fs = std::move(fs);
 		return s;

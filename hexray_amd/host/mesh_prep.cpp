@@ -155,6 +155,7 @@ bool MeshData::load_obj(const std::string& path)
 
 	// prepareTriangles (src/mesh.cpp:370-396)
 	if (normals.size() <= 1) faceted = true;
+	if (defer_triangle_prep && !auto_smooth) return true;   // left to the render module; auto-smoothing (begin_render) needs gnormal here
 	for (hxr_triangle& t : triangles) {
 		const V3 &A = vertices[t.v[0]], &B = vertices[t.v[1]], &C = vertices[t.v[2]];
 		V3 AB = B - A, AC = C - A, N = cross(AB, AC);

@@ -19,6 +19,7 @@ struct KdStats {
 };
 
 struct MeshData {
+	bool defer_triangle_prep = false;   // set before load_obj: leave the derived triangle fields zero (hxr_scene_options.device_prepare_triangles)
 	bool faceted = false, backface_culling = false, use_kd = true, auto_smooth = false, recenter = false;
 	std::vector<V3> vertices, normals, uvs;   // entry 0 is the sentinel
 	std::vector<hxr_triangle> triangles;

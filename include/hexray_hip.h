@@ -343,6 +343,10 @@ typedef struct hxr_scene_options {
 	                             kd-trees for itself.  Default (0): they are traced in place, on a per-lane
 	                             stack, inside the render kernel.  Same rays, same work counters; the frames of the two settings
 	                             differ at float rounding level (summation order). */
+	int32_t device_prepare_triangles; /* 1: Mesh::prepareTriangles (src/mesh.cpp:370-396) runs on the GPU at hxr_scene_create: the derived fields of
+	                             hxr_triangle (gnormal, AB, AC, ABcrossAC, dNdx, dNdy) are computed there from the v / t numbers and are not read
+	                             from the descriptor (the host loader's HXH_GPU_PREPARE_TRIANGLES leaves them zero).  hxr_scene_verify_tables
+	                             compares them with a complete descriptor's. */
 } hxr_scene_options;
 
 /* hxr_scene_create with options (NULL = defaults = hxr_scene_create). */

@@ -75,3 +75,36 @@ def test_device_kd_build_argument_checks(gpu):
     small = np.zeros(1, dtype=hx.KD_NODE_DTYPE)
     leaves = np.zeros(1, dtype=np.int32)
     assert lib.hxr_kd_build_device(hs.desc, 2, small.ctypes.data, 1, leaves.ctypes.data, 1, None, None, None, None) < 0
+
+
+def test_triangles_prepared_on_the_gpu_equal_the_hosts(gpu):
+    """Mesh::prepareTriangles as a kernel (hxr_scene_options.device_prepare_triangles): gnormal, AB, AC, ABcrossAC, dNdx, dNdy of every
+    triangle, bit for bit what the host loader computes (signed zeros included) -- for every reference mesh that is not recentred
+    (a recentred mesh's vertices move after the reference has derived these fields from them)."""
+    hx = gpu
+    scene = os.path.join(ROOT, "tests", "golden", "meshes_not_recentred.hexray")
+    full = hx.HostScene(scene)
+    bare = hx.HostScene(scene, gpu_prepare_triangles=True, gpu_kd_build=True)
+    d = SceneDesc.from_address(bare.desc)
+    assert d.num_triangles == 18031
+    assert all(d.triangles[k].AB[c] == 0 and d.triangles[k].gnormal[c] == 0 for k in (0, 7, d.num_triangles - 1) for c in range(3))   # nothing prepared on the host
+    ds = hx.DeviceScene(bare, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD, device_prepare_triangles=True)
+    assert ds.verify_tables(full) == 0          # triangle records AND the hot records gathered from them
+    assert hx.DeviceScene(bare, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD).verify_tables(full) > 0   # the check does see unprepared records
+
+
+def test_frame_from_triangles_prepared_on_the_gpu(gpu):
+    """meshes.hexray through a descriptor with neither trees nor prepared triangles.  Its teapot is recentred, so the re-derived edge
+    vectors differ from the reference's in the last bits: same rays, an image well inside the 1e-4 bar."""
+    hx = gpu
+    ov = hx.overlay_text(width=480, height=270, dof=True, num_samples=4)
+    want_scene = hx.DeviceScene(hx.HostScene(scene_path("meshes.hexray"), ov))
+    p = hx.frame_params(collect_counters=True)
+    want = want_scene.render(p)
+    bare = hx.HostScene(scene_path("meshes.hexray"), ov, gpu_prepare_triangles=True, gpu_kd_build=True)
+    ds = hx.DeviceScene(bare, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD, device_prepare_triangles=True)
+    got = ds.render(p)
+    rms = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2, axis=(0, 1)))
+    assert rms.max() <= 1e-4, rms
+    a, b = ds.counters(), want_scene.counters()
+    assert a["camera_samples"] == b["camera_samples"] and abs(a["raycasts"] - b["raycasts"]) <= 1e-4 * b["raycasts"]
