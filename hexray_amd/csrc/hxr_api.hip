@@ -90,6 +90,7 @@ struct hxr_scene {
 	std::vector<TreeStats> tree_stats;   // per mesh: the tree actually walked
 	double kd_build_ms = 0;              // HXR_ACCEL_REFERENCE_DEVICE_BUILD: time of the kd builds on the GPU, all meshes
 	const hxr_triangle* d_triangles = nullptr;   // the triangle records in HBM (hxr_scene_verify_tables reads them back)
+	std::vector<char> hf_raw;            // per heightfield: created from hxr_heightfield::raw_heights (blur / box / normals computed here)
 	// per-frame scratch, grown on demand
 	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
 	float* d_scratch = nullptr;     size_t scratch_bytes = 0;  // sharded-AA full frame
@@ -222,8 +223,10 @@ int validate(const hxr_scene_desc* d)
 		const int64_t cells = (int64_t)h.W * h.H;
 		auto floats_ok = [&](int64_t first, int64_t n) { return first >= 0 && first <= d->f32_pool_size && n <= d->f32_pool_size - first; };
 		const bool tables = h.first_maxh >= 0 && h.first_highmap >= 0;
+		const bool normals_ok = h.raw_heights ? true : (h.first_normal >= 0 && h.first_normal <= d->f64_pool_size / 3 && cells <= d->f64_pool_size / 3 - h.first_normal);
+		const bool raw_ok = !h.raw_heights || (!tables && h.blur_radius >= 0 && h.blur_radius <= 128 && (h.blur_radius == 0 || floats_ok(h.first_blur_kernel, (int64_t)h.blur_radius * h.blur_radius)));
 		if (h.W <= 0 || h.H <= 0 || cells > (1ll << 30) || !floats_ok(h.first_height, cells) || (tables && (!floats_ok(h.first_maxh, cells) || !floats_ok(h.first_highmap, cells * 16))) ||
-		    h.max_k < 0 || h.max_k > 16 || h.first_normal < 0 || h.first_normal > d->f64_pool_size / 3 || cells > d->f64_pool_size / 3 - h.first_normal) {
+		    h.max_k < 0 || h.max_k > 16 || !normals_ok || !raw_ok) {
 			set_err("heightfield %lld: a table range lies outside the descriptor", (long long)i);
 			return HXR_E_INVALID;
 		}
@@ -1073,6 +1076,23 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		o.heights = d_f32 + h.first_height;
 		o.normals = d_f64 + h.first_normal * 3;
 		if (h.W <= 0 || h.H <= 0 || h.first_height < 0 || h.first_height + (int64_t)h.W * h.H > d->f32_pool_size) { set_err("bad heightfield ranges"); return fail(); }
+		s->hf_raw.push_back(h.raw_heights ? 1 : 0);
+		if (h.raw_heights) {
+			// the descriptor stops at the image: blur, y extent of the box and normals as kernels (the maxima tables follow below)
+			const int cells = h.W * h.H, grid = std::min((cells + 255) / 256, 4096);
+			void *ph = nullptr, *pn = nullptr, *pr = nullptr;
+			if (s->arena.alloc((size_t)cells * sizeof(float), &ph) || s->arena.alloc((size_t)cells * 3 * sizeof(double), &pn) || s->arena.alloc(2 * sizeof(float), &pr)) return fail();
+			if (h.blur_radius > 0) hipLaunchKernelGGL(hxr_hf_blur_kernel, dim3(grid), dim3(256), 0, nullptr, o.heights, h.W, h.H, d_f32 + h.first_blur_kernel, h.blur_radius, (float*)ph);
+			else if (hipMemcpyAsync(ph, o.heights, (size_t)cells * sizeof(float), hipMemcpyDeviceToDevice, nullptr) != hipSuccess) { set_err("hipMemcpyAsync failed"); return fail(); }
+			hipLaunchKernelGGL(hxr_hf_range_kernel, dim3(1), dim3(1024), 0, nullptr, (const float*)ph, cells, (float*)pr);
+			hipLaunchKernelGGL(hxr_hf_normals_kernel, dim3(grid), dim3(256), 0, nullptr, (const float*)ph, h.W, h.H, (double*)pn);
+			float range[2] = {0, 0};
+			if (hipGetLastError() != hipSuccess || hipMemcpy(range, pr, sizeof range, hipMemcpyDeviceToHost) != hipSuccess) { set_err("heightfield preparation kernels failed"); return fail(); }
+			o.bbox_min[0] = 0; o.bbox_min[1] = range[0]; o.bbox_min[2] = 0;   // src/heightfield.cpp:213-216
+			o.bbox_max[0] = h.W; o.bbox_max[1] = range[1]; o.bbox_max[2] = h.H;
+			o.heights = (const float*)ph;
+			o.normals = (const double*)pn;
+		}
 		if (h.first_maxh >= 0 && h.first_highmap >= 0) {
 			o.max_h = d_f32 + h.first_maxh;
 			o.high_map = d_f32 + h.first_highmap;
@@ -1137,7 +1157,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		double lo[3], hi[3];
 		bool bounded = true;
 		if (g.type == HXR_GEOM_MESH) { memcpy(lo, d->meshes[g.ref].bbox_min, sizeof lo); memcpy(hi, d->meshes[g.ref].bbox_max, sizeof hi); }
-		else if (g.type == HXR_GEOM_HEIGHTFIELD) { memcpy(lo, d->heightfields[g.ref].bbox_min, sizeof lo); memcpy(hi, d->heightfields[g.ref].bbox_max, sizeof hi); }
+		else if (g.type == HXR_GEOM_HEIGHTFIELD) { memcpy(lo, hfs[(size_t)g.ref].bbox_min, sizeof lo); memcpy(hi, hfs[(size_t)g.ref].bbox_max, sizeof hi); }   // the module's own copy: a raw heightfield's box is computed here
 		else if (g.type == HXR_GEOM_SPHERE) for (int c = 0; c < 3; c++) { lo[c] = g.p[c] - g.p[3]; hi[c] = g.p[c] + g.p[3]; }
 		else if (g.type == HXR_GEOM_CUBE) for (int c = 0; c < 3; c++) { lo[c] = g.p[c] - g.p[3]; hi[c] = g.p[c] + g.p[3]; }
 		else bounded = false;   // planes (possibly unlimited) and CSG are always scanned
@@ -1661,10 +1681,28 @@ int hxr_scene_verify_tables(const hxr_scene* s, const hxr_scene_desc* d, int64_t
 		HIP_TRY(hipMemcpy(mh.data(), hfs[(size_t)i].max_h, mh.size() * sizeof(float), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hm.data(), hfs[(size_t)i].high_map, hm.size() * sizeof(float), hipMemcpyDeviceToHost));
 		if (hfs[(size_t)i].max_k != h.max_k) ++*mismatches;
+		// a scene created from raw heights blurred them itself, in another summation order than the host: heights, and the maxima of
+		// heights, then agree to float rounding (a few 1e-7 of the height range) instead of bit for bit
+		const bool raw = (size_t)i < s->hf_raw.size() && s->hf_raw[(size_t)i] && !h.raw_heights;
+		const float tol = raw ? 1e-5f * (float)std::max(1.0, h.bbox_max[1] - h.bbox_min[1]) : 0.0f;
+		auto differs = [&](float a, float b) { return raw ? !(std::fabs(a - b) <= tol) : a != b; };
 		for (size_t c = 0; c < cells; c++) {
-			if (mh[c] != d->f32_pool[h.first_maxh + (int64_t)c]) ++*mismatches;
+			if (differs(mh[c], d->f32_pool[h.first_maxh + (int64_t)c])) ++*mismatches;
 			for (int k = 0; k < h.max_k; k++)
-				if (hm[c * 16 + k] != d->f32_pool[h.first_highmap + (int64_t)(c * 16 + k)]) ++*mismatches;
+				if (differs(hm[c * 16 + k], d->f32_pool[h.first_highmap + (int64_t)(c * 16 + k)])) ++*mismatches;
+		}
+		if (raw) {
+			std::vector<float> hts(cells);
+			std::vector<double> nrm(cells * 3);
+			HIP_TRY(hipMemcpy(hts.data(), hfs[(size_t)i].heights, hts.size() * sizeof(float), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(nrm.data(), hfs[(size_t)i].normals, nrm.size() * sizeof(double), hipMemcpyDeviceToHost));
+			for (size_t c = 0; c < cells; c++) {
+				if (differs(hts[c], d->f32_pool[h.first_height + (int64_t)c])) ++*mismatches;
+				for (int k = 0; k < 3; k++)
+					if (!(std::fabs(nrm[c * 3 + k] - d->f64_pool[(h.first_normal + (int64_t)c) * 3 + k]) <= 1e-5)) ++*mismatches;
+			}
+			for (int k = 0; k < 3; k++)
+				if (!(std::fabs(hfs[(size_t)i].bbox_min[k] - h.bbox_min[k]) <= tol) || !(std::fabs(hfs[(size_t)i].bbox_max[k] - h.bbox_max[k]) <= tol)) ++*mismatches;
 		}
 	}
 	return 0;

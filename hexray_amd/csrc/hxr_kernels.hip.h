@@ -2599,6 +2599,66 @@ __global__ void hxr_expand_hot_kernel(const hxr_triangle* __restrict__ tris, con
 	}
 }
 
+// hxr_heightfield::raw_heights -- the rest of Heightfield::fillProperties (src/heightfield.cpp:173-261) on the GPU, one texel per lane.
+// The Gaussian blur (src/heightfield.cpp:189-212): taps outside the image count as 0; the taps of a texel are added up in the
+// reference's loop order (dy outer, dx inner) with a fused multiply-add each.  The host loader's sums of the same taps are grouped by
+// its compiler's vectoriser (eight partial sums per row), so the two agree to float rounding, not bit for bit.
+__global__ void hxr_hf_blur_kernel(const float* __restrict__ grey, int W, int H, const float* __restrict__ g, int R, float* __restrict__ heights)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * H; i += gridDim.x * blockDim.x) {
+		const int x = i % W, y = i / W;
+		float sum = 0;
+		for (int dy = -R + 1; dy < R; dy++) {
+			const int yy = y + dy;
+			if (yy < 0 || yy >= H) continue;
+			const float* row = grey + (size_t)yy * W;
+			const float* gr = g + (size_t)(dy < 0 ? -dy : dy) * R;
+			for (int dx = -R + 1; dx < R; dx++) {
+				const int xx = x + dx;
+				if (xx >= 0 && xx < W) sum = fmaf(gr[dx < 0 ? -dx : dx], row[xx], sum);
+			}
+		}
+		heights[i] = sum;
+	}
+}
+
+// lowest and highest height (the y extent of the bounding box, src/heightfield.cpp:213-216): ONE workgroup, out[0] = min, out[1] = max
+__global__ __launch_bounds__(1024) void hxr_hf_range_kernel(const float* __restrict__ heights, int n, float* out)
+{
+	__shared__ float s_lo[1024], s_hi[1024];
+	float lo = 1e17f, hi = -1e17f;
+	for (int i = threadIdx.x; i < n; i += 1024) { lo = fminf(lo, heights[i]); hi = fmaxf(hi, heights[i]); }
+	s_lo[threadIdx.x] = lo;
+	s_hi[threadIdx.x] = hi;
+	__syncthreads();
+	for (int step = 512; step > 0; step >>= 1) {
+		if ((int)threadIdx.x < step) { s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + step]); s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + step]); }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { out[0] = s_lo[0]; out[1] = s_hi[0]; }
+}
+
+// the per-texel normals (src/heightfield.cpp:237-253): unit(cross((0, hy - h0, 1), (1, hx - h0, 0))) = unit(-(hx - h0), 1, -(hy - h0)); the last
+// column and the last row repeat their neighbours
+__global__ void hxr_hf_normals_kernel(const float* __restrict__ heights, int W, int H, double* __restrict__ normals)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * H; i += gridDim.x * blockDim.x) {
+		const int x = min(i % W, W - 2), y = min(i / W, H - 2);
+		double n[3] = {0, 0, 0};
+		if (x >= 0 && y >= 0) {
+			const float h0 = heights[(size_t)y * W + x];
+			const double nx = (double)(h0 - heights[(size_t)y * W + x + 1]), nz = (double)(h0 - heights[(size_t)(y + 1) * W + x]);
+			const double k = 1.0 / sqrt(fma(nx, nx, fma(nz, nz, 1.0)));
+			n[0] = nx * k;
+			n[1] = k;
+			n[2] = nz * k;
+		}
+		normals[(size_t)i * 3 + 0] = n[0];
+		normals[(size_t)i * 3 + 1] = n[1];
+		normals[(size_t)i * 3 + 2] = n[2];
+	}
+}
+
 // Heightfield::maxH (src/heightfield.cpp:222-235): the highest of the four corners of a cell (fewer at the last row / column)
 __global__ void hxr_hf_maxh_kernel(const float* __restrict__ heights, int W, int H, float* max_h)
 {

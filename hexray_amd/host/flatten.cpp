@@ -259,7 +259,11 @@ struct Loader {
 			double blur = 0;
 			b.get_double("blur", blur, 0, 1000);
 			if (!img.ok()) throw ParseError(b.line_end, "Heightfield: could not load the height bitmap");
-			hd.build(img, blur, !fs.gpu_heightfield_tables);
+			const auto t0 = std::chrono::steady_clock::now();
+			hd.build(img, blur, !fs.gpu_heightfield_tables, fs.gpu_heightfield_blur);
+			if (getenv("HXH_TIMING"))
+				fprintf(stderr, "[hxh] heightfield %dx%d: blur %g + normals%s %.1f ms\n", hd.W, hd.H, blur, fs.gpu_heightfield_tables ? "" : " + maxima tables",
+				        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 			hxr_heightfield h;
 			memset(&h, 0, sizeof h);
 			h.W = hd.W;
@@ -279,7 +283,15 @@ struct Loader {
 				h.first_highmap = int64_t(fs.f32_pool.size());
 				fs.f32_pool.insert(fs.f32_pool.end(), hd.high_map.begin(), hd.high_map.end());
 			}
-			h.first_normal = add_vectors(hd.normals) / 3;
+			if (fs.gpu_heightfield_blur) {
+				h.raw_heights = 1;
+				h.first_normal = -1;
+				h.blur_radius = hd.blur_radius;
+				h.first_blur_kernel = int64_t(fs.f32_pool.size());
+				fs.f32_pool.insert(fs.f32_pool.end(), hd.blur_kernel.begin(), hd.blur_kernel.end());
+			} else {
+				h.first_normal = add_vectors(hd.normals) / 3;
+			}
 			g.ref = int(fs.heightfields.size());
 			fs.heightfields.push_back(h);
 		}
@@ -538,7 +550,7 @@ void FlatScene::refresh_desc()
 #undef HXH_TABLE
 }
 
-std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build, bool gpu_prepare_triangles)
+std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build, bool gpu_prepare_triangles, bool gpu_heightfield_blur)
 {
 	std::ifstream in(scene_path);
 	if (!in) throw std::runtime_error("Cannot open scene file `" + scene_path + "'!");
@@ -548,7 +560,8 @@ std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::
 	if (!overlay_text.empty()) merge_overlay(blocks, parse_scene_text(overlay_text, "<overlay>"));
 
 	auto fs = std::make_unique<FlatScene>();
-	fs->gpu_heightfield_tables = gpu_heightfield_tables;
+	fs->gpu_heightfield_tables = gpu_heightfield_tables || gpu_heightfield_blur;
+	fs->gpu_heightfield_blur = gpu_heightfield_blur;
 	fs->gpu_kd_build = gpu_kd_build;
 	fs->gpu_prepare_triangles = gpu_prepare_triangles;
 	// defaults, src/scene.h:244-269

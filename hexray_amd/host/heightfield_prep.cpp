@@ -6,12 +6,32 @@
 
 namespace hxh {
 
-void HeightfieldData::build(Image& bmp, double blur, bool maxima_tables)
+void HeightfieldData::build(Image& bmp, double blur, bool maxima_tables, bool raw)
 {
 	W = bmp.w;
 	H = bmp.h;
 	heights.assign(size_t(W) * H, 0.0f);
 	float lo = 1e17f, hi = -1e17f;
+	blur_kernel.clear();
+	blur_radius = 0;
+	if (raw) {   // hxr_heightfield::raw_heights: everything below happens on the GPU
+		for (int y = 0; y < H; y++)
+			for (int x = 0; x < W; x++) heights[size_t(y) * W + x] = bmp.intensity(x, y);
+		if (blur > 0) {
+			blur_radius = std::min(128, int(std::floor(float(3 * blur) + 0.5f)));
+			blur_kernel.resize(size_t(blur_radius) * blur_radius);
+			for (int y = 0; y < blur_radius; y++)
+				for (int x = 0; x < blur_radius; x++)
+					blur_kernel[size_t(y) * blur_radius + x] = float(std::exp(-(double(x) * x + double(y) * y) / (2 * blur * blur)) / (2 * kPi * (blur * blur)));
+		}
+		bbox_min = V3(0, 0, 0);
+		bbox_max = V3(W, 0, H);
+		max_h.clear();
+		normals.clear();
+		high_map.clear();
+		max_k = 0;
+		return;
+	}
 	if (blur <= 0) {
 		for (int y = 0; y < H; y++)
 			for (int x = 0; x < W; x++) {

@@ -16,7 +16,10 @@ struct HeightfieldData {
 	std::vector<float> high_map;   // 16 floats per cell
 	V3 bbox_min, bbox_max;
 
-	void build(Image& bmp, double blur, bool maxima_tables = true);   // false: max_h / high_map / max_k are left to the render module (hxr_heightfield::first_maxh = -1)
+	std::vector<float> blur_kernel;   // raw mode: the R x R Gaussian table
+	int blur_radius = 0;
+	// `raw`: stop after the image: heights = unblurred intensities + the Gaussian table; blur, box, normals and maxima are left to the render module
+	void build(Image& bmp, double blur, bool maxima_tables = true, bool raw = false);   // false: max_h / high_map / max_k are left to the render module (hxr_heightfield::first_maxh = -1)
 };
 
 }  // namespace hxh

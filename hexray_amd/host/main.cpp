@@ -21,7 +21,7 @@ static void usage()
 	       "              [--gi on|off] [--paths N] [--mode auto|single|aa|mc|prepass] [--seed S] [--device D]\n"
 	       "              [--frames N] [--out frame.bmp|frame.exr|frame.raw] [--counters] [--accel reference|sah|device-build]\n"
 	       "              [--no-adaptive-schedule] [--deferred-rays] [--gpus N | --devices a,b,...] [--tile T] [--progress]\n"
-	       "              [--interactive FRAMES] [--fovea RADIUS]\n");
+	       "              [--interactive FRAMES] [--fovea RADIUS] [--gpu-heightfield-blur]\n");
 }
 
 int main(int argc, char** argv)
@@ -34,6 +34,7 @@ int main(int argc, char** argv)
 	int device = 0, frames = 1;
 	std::vector<int> devices;   // more than one entry: the frame is sharded over them (hxr_group_*)
 	bool progress = false;
+	bool gpu_blur = false;        // Heightfield blur / box / normals on the GPU as well (hxr_heightfield::raw_heights)
 	int interactive_frames = 0;   // > 0: the interactive loop (gameloop(), src/main.cpp:443-504) over a scripted camera path
 	hxr_scene_options opt;
 	memset(&opt, 0, sizeof opt);
@@ -65,6 +66,7 @@ int main(int argc, char** argv)
 		else if (a == "--progress") progress = true;
 		else if (a == "--interactive") interactive_frames = atoi(next());
 		else if (a == "--fovea") fp.foveated_radius = atoi(next());
+		else if (a == "--gpu-heightfield-blur") gpu_blur = true;
 		else if (a == "-h" || a == "--help") { usage(); return 0; }
 		else if (!a.empty() && a[0] != '-') scene = a;
 		else { usage(); return 2; }
@@ -75,7 +77,7 @@ int main(int argc, char** argv)
 
 	char err[1024] = "";
 	// the module builds the heightfield maxima tables on the GPU, and with --accel device-build the kd-trees (Mesh::buildKD) as well
-	const unsigned load_flags = HXH_GPU_HEIGHTFIELD_TABLES | (opt.accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD ? HXH_GPU_KD_BUILD : 0u);
+	const unsigned load_flags = HXH_GPU_HEIGHTFIELD_TABLES | (opt.accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD ? HXH_GPU_KD_BUILD : 0u) | (gpu_blur ? HXH_GPU_HEIGHTFIELD_BLUR : 0u);
 	hxh_scene* hs = hxh_scene_load_ex(scene.c_str(), overlay.c_str(), load_flags, err, sizeof err);
 	if (!hs) {
 		printf("Could not parse the scene file (%s)!\n%s\n", scene.c_str(), err);

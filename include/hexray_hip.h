@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HXR_ABI_VERSION 1u
+#define HXR_ABI_VERSION 2u   /* 2: hxr_heightfield grew raw_heights / blur_radius / first_blur_kernel */
 
 /* ------------------------------------------------------------------ error codes */
 enum {
@@ -110,7 +110,14 @@ typedef struct hxr_heightfield {
 	int64_t first_height;    /* f32_pool, W*H            heights[y*W+x] */
 	int64_t first_maxh;      /* f32_pool, W*H            maxH[y*W+x];  -1 together with first_highmap = not provided: the module    */
 	int64_t first_highmap;   /* f32_pool, W*H*16         highMap[y*W+x].h[k]   builds both on the GPU from the heights (max_k too) */
-	int64_t first_normal;    /* f64_pool, counted in 3-double VECTORS like hxr_mesh: normals[y*W+x] */
+	int64_t first_normal;    /* f64_pool, counted in 3-double VECTORS like hxr_mesh: normals[y*W+x]; -1 with raw_heights */
+	/* raw_heights = 1: the whole of Heightfield::fillProperties after the image load (src/heightfield.cpp:173-261) is left to the module,
+	   which runs it on the GPU at hxr_scene_create: `first_height` holds the UNBLURRED intensities, the Gaussian table of the blur is
+	   handed over (its R*R entries come from the host's exp()), and heights, bounding box (bbox_min[1] / bbox_max[1] are ignored),
+	   normals and maxima tables are derived there (first_maxh = first_highmap = first_normal = -1).  For the HIP module only. */
+	int32_t raw_heights;
+	int32_t blur_radius;       /* R of the table: taps dx, dy = -(R-1) .. R-1; 0 = no blur */
+	int64_t first_blur_kernel; /* f32_pool, R*R: g[|dy|*R + |dx|] */
 } hxr_heightfield;
 
 /* Bitmap (reference src/bitmap.h:32-63): float RGB texels, row-major, 3 floats per texel. */
@@ -376,7 +383,9 @@ int hxr_scene_tree_stats(const hxr_scene* scene, int mesh, int64_t* nodes, int64
 /* Checks the tables the module prepared on the GPU at hxr_scene_create -- the leaf-ordered hot triangle records and, when the
  * scene was created from a descriptor WITHOUT heightfield maxima tables, those tables -- against the host's: every hot record is
  * re-derived from `desc`, the maxima tables are compared with the ones `desc` carries (pass the complete descriptor here).
- * *mismatches receives the number of differing records / values: the preparation is pure copies and maxima, so it must be 0. */
+ * *mismatches receives the number of differing records / values: the preparation is pure copies and maxima, so it must be 0.
+ * A scene created from hxr_heightfield::raw_heights is compared (heights, box, normals, maxima) with a tolerance of 1e-5 of the height range:
+ * its blur adds the same taps in another order than the host's. */
 int hxr_scene_verify_tables(const hxr_scene* scene, const hxr_scene_desc* desc, int64_t* mismatches);
 
 /* Per-frame camera update (Camera::beginFrame, src/camera.cpp:30-63, after move/rotate). */

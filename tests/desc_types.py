@@ -33,7 +33,8 @@ class Mesh(ctypes.Structure):
 
 class Heightfield(ctypes.Structure):
     _fields_ = [("W", c_int32), ("H", c_int32), ("max_k", c_int32), ("use_optimization", c_int32), ("bbox_min", c_double * 3),
-                ("bbox_max", c_double * 3), ("first_height", c_int64), ("first_maxh", c_int64), ("first_highmap", c_int64), ("first_normal", c_int64)]
+                ("bbox_max", c_double * 3), ("first_height", c_int64), ("first_maxh", c_int64), ("first_highmap", c_int64), ("first_normal", c_int64),
+                ("raw_heights", c_int32), ("blur_radius", c_int32), ("first_blur_kernel", c_int64)]
 
 
 class Bitmap(ctypes.Structure):

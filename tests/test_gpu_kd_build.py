@@ -108,3 +108,27 @@ def test_frame_from_triangles_prepared_on_the_gpu(gpu):
     assert rms.max() <= 1e-4, rms
     a, b = ds.counters(), want_scene.counters()
     assert a["camera_samples"] == b["camera_samples"] and abs(a["raycasts"] - b["raycasts"]) <= 1e-4 * b["raycasts"]
+
+
+def test_heightfield_prepared_on_the_gpu_from_the_raw_image(gpu):
+    """hxr_heightfield::raw_heights: Gaussian blur, bounding box, normals and maxima tables of Heightfield::fillProperties as kernels.
+    The blur adds the same taps in another order than the host loader (whose order is its compiler's vectorisation), so the tables
+    agree to float rounding -- hxr_scene_verify_tables' tolerance -- and the frame stays well inside the 1e-4 bar."""
+    hx = gpu
+    ov = hx.overlay_text(width=480, height=270, dof=True, num_samples=4)
+    full = hx.HostScene(scene_path("heightfield.hexray"), ov)
+    bare = hx.HostScene(scene_path("heightfield.hexray"), ov, gpu_heightfield_blur=True)
+    h = SceneDesc.from_address(bare.desc).heightfields[0]
+    assert h.raw_heights == 1 and h.blur_radius == 8 and h.first_normal == -1 and h.first_maxh == -1 and h.first_highmap == -1
+    ds = hx.DeviceScene(bare)
+    assert ds.verify_tables(full) == 0
+    p = hx.frame_params(collect_counters=True)
+    got = ds.render(p)
+    ref = hx.DeviceScene(full)
+    want = ref.render(p)
+    rms = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2, axis=(0, 1)))
+    assert rms.max() <= 1e-4, rms
+    a, b = ds.counters(), ref.counters()
+    assert a["camera_samples"] == b["camera_samples"]
+    for k in ("raycasts", "hf_calls", "hf_tri_tests"):
+        assert abs(a[k] - b[k]) <= 2e-3 * b[k], (k, a[k], b[k])
