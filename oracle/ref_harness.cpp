@@ -397,6 +397,52 @@ int main()
 	}
 	close_list();
 
+	// 9. NESTED CSG (src/geometry.cpp:149-194 is generic over Geometry*): an inner operation over a sphere and a cube is itself the left or
+	//    the right operand of an outer operation whose other operand is a second sphere.  Appended last, so that the random sequence of the
+	//    lists above -- and with it every earlier vector -- stays what it was.
+	open_list("csg_nested");
+	for (int i = 0; i < 576; i++) {
+		Sphere s;
+		s.O = rand_vec(1.5);
+		s.R = uni(0.8, 3);
+		Cube c;
+		c.O = rand_vec(1.5);
+		c.side = uni(1, 5);
+		c.beginFrame();
+		Sphere s2;
+		s2.O = rand_vec(2);
+		s2.R = uni(0.8, 3);
+		const char* kinds[3] = {"CSGUnion", "CSGInter", "CSGDiff"};
+		auto make = [](int k) -> CSGBase* { return k == 0 ? (CSGBase*)new CSGUnion : k == 1 ? (CSGBase*)new CSGInter : (CSGBase*)new CSGDiff; };
+		const int inner_kind = i % 3, outer_kind = (i / 3) % 3, inner_is_left = (i / 9) % 2;
+		CSGBase* inner = make(inner_kind);
+		CSGBase* outer = make(outer_kind);
+		CannedBlock pi;
+		pi.geometries["left"] = &s;
+		pi.geometries["right"] = &c;
+		inner->fillProperties(pi);
+		CannedBlock po;
+		po.geometries["left"] = inner_is_left ? (Geometry*)inner : (Geometry*)&s2;
+		po.geometries["right"] = inner_is_left ? (Geometry*)&s2 : (Geometry*)inner;
+		outer->fillProperties(po);
+		Ray r;
+		r.start = rand_vec(10);
+		Vector t = rand_vec(2.5) - r.start;
+		t.normalize();
+		r.dir = t;
+		IntersectionInfo info;
+		bool ok = outer->intersect(r, info);
+		sep();
+		printf("{\"inner\":\"%s\",\"outer\":\"%s\",\"inner_is_left\":%d,\"sphere_O\":%s,\"sphere_R\":%s,\"cube_O\":%s,\"cube_side\":%s,\"sphere2_O\":%s,\"sphere2_R\":%s,\"o\":%s,\"d\":%s,",
+		       kinds[inner_kind], kinds[outer_kind], inner_is_left, vec(s.O).c_str(), num(s.R).c_str(), vec(c.O).c_str(), num(c.side).c_str(), vec(s2.O).c_str(),
+		       num(s2.R).c_str(), vec(r.start).c_str(), vec(r.dir).c_str());
+		emit_hit(ok, info);
+		printf("}");
+		delete outer;
+		delete inner;
+	}
+	close_list();
+
 	printf("\n}\n");
 	return 0;
 }

@@ -117,6 +117,26 @@ def test_csg(golden):
         _check_hit(lib.hxo_geometry_intersect, hs.desc, 1 + 3 * i + 2, c, out, rel=1e-9)
 
 
+def test_csg_nested(golden):
+    """An operation over a sphere and a cube as the left / right operand of an outer operation (CSGBase::intersect is generic over Geometry*)."""
+    lib = oracle_lib()
+    text = ""
+    for i, c in enumerate(golden["csg_nested"]):
+        inner, other = f"in{i}", f"ns{i}"
+        text += (f"Sphere is{i} {{\n\tO {vec_text(c['sphere_O'])}\n\tR {c['sphere_R']!r}\n}}\n"
+                 f"Cube ic{i} {{\n\tO {vec_text(c['cube_O'])}\n\tside {c['cube_side']!r}\n}}\n"
+                 f"{c['inner']} {inner} {{\n\tleft is{i}\n\tright ic{i}\n}}\n"
+                 f"Sphere {other} {{\n\tO {vec_text(c['sphere2_O'])}\n\tR {c['sphere2_R']!r}\n}}\n"
+                 f"{c['outer']} out{i} {{\n\tleft {inner if c['inner_is_left'] else other}\n\tright {other if c['inner_is_left'] else inner}\n}}\n")
+    hs = load_elements(text)
+    out = (ctypes.c_double * 12)()
+    hits = 0
+    for i, c in enumerate(golden["csg_nested"]):
+        _check_hit(lib.hxo_geometry_intersect, hs.desc, 1 + 5 * i + 4, c, out, rel=1e-9)
+        hits += c["hit"]
+    assert hits > 200
+
+
 def test_node_intersect(golden):
     """Node::intersect: ray into object space, hit back to world space (reference src/geometry.cpp:196-208)."""
     lib = oracle_lib()
