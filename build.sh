@@ -28,19 +28,22 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	HF_TU_FLAGS="-O2"
 	API_TU_FLAGS="-O3"
 	# stale objects must not survive a failed recompile (a bare `wait` returns 0 whatever the jobs did)
-	rm -f build/hxr_kernels_mesh.o build/hxr_kernels_mesh2.o build/hxr_kernels_heightfield.o build/hxr_api.o build/hxr_kd_build.o
+	rm -f build/hxr_kernels_mesh.o build/hxr_kernels_mesh2.o build/hxr_kernels_heightfield.o build/hxr_api.o build/hxr_kd_build.o build/hxr_kernels_nested.o
 	hipcc $HIPFLAGS $MESH_TU_FLAGS -c -o build/hxr_kernels_mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
 	p1=$!
 	hipcc $HIPFLAGS $HF_TU_FLAGS -c -o build/hxr_kernels_heightfield.o hexray_amd/csrc/hxr_kernels_heightfield.hip &
 	p2=$!
 	hipcc $HIPFLAGS $MESH_TU_FLAGS -c -o build/hxr_kernels_mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
 	p3=$!
-	hipcc $HIPFLAGS $API_TU_FLAGS -c -o build/hxr_kd_build.o hexray_amd/csrc/hxr_kd_build.hip || { kill $p1 $p2 $p3 2>/dev/null; exit 1; }
-	hipcc $HIPFLAGS $API_TU_FLAGS -c -o build/hxr_api.o hexray_amd/csrc/hxr_api.hip || { kill $p1 $p2 $p3 2>/dev/null; exit 1; }
+	hipcc $HIPFLAGS $HF_TU_FLAGS -c -o build/hxr_kernels_nested.o hexray_amd/csrc/hxr_kernels_nested.hip &
+	p4=$!
+	hipcc $HIPFLAGS $API_TU_FLAGS -c -o build/hxr_kd_build.o hexray_amd/csrc/hxr_kd_build.hip || { kill $p1 $p2 $p3 $p4 2>/dev/null; exit 1; }
+	hipcc $HIPFLAGS $API_TU_FLAGS -c -o build/hxr_api.o hexray_amd/csrc/hxr_api.hip || { kill $p1 $p2 $p3 $p4 2>/dev/null; exit 1; }
 	wait $p1 || exit 1
 	wait $p2 || exit 1
 	wait $p3 || exit 1
-	hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip.so build/hxr_api.o build/hxr_kd_build.o build/hxr_kernels_mesh.o build/hxr_kernels_mesh2.o build/hxr_kernels_heightfield.o
+	wait $p4 || exit 1
+	hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip.so build/hxr_api.o build/hxr_kd_build.o build/hxr_kernels_mesh.o build/hxr_kernels_mesh2.o build/hxr_kernels_heightfield.o build/hxr_kernels_nested.o
 fi
 if [ "$what" = all ] || [ "$what" = cli ]; then
 	g++ $CXXFLAGS -o hexray_amd/bin/hexray hexray_amd/host/main.cpp -Lhexray_amd/lib -lhexray_host -lhexray_hip \

@@ -26,6 +26,7 @@ HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_CONTINUE)
 HXR_VARIANTS_MESH_LANEWALK(HXR_DECLARE_EXTERN_CONTINUE)
 HXR_VARIANTS_MESH_OTHER(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_HEIGHTFIELD(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_NESTED_CSG(HXR_DECLARE_EXTERN)
 
 namespace {
 
@@ -159,6 +160,28 @@ void shader_fanout(const hxr_scene_desc* d, int si, int depth, int& rays, int& p
 	}
 }
 
+// depth of the operation tree below CSG geometry `gi` (an operation over primitives = 1); -1: an operand index outside the table,
+// -2: an operand that is neither an analytic primitive nor an operation; anything deeper than 16 (a cycle) counts as 17
+int csg_depth(const hxr_scene_desc* d, int gi, int level)
+{
+	if (level > 16) return 17;
+	const hxr_geometry& g = d->geometries[gi];
+	int deepest = level;
+	for (int side = 0; side < 2; side++) {
+		const int op = side ? g.right : g.left;
+		if (op < 0 || op >= d->num_geometries) return -1;
+		const int t = d->geometries[op].type;
+		if (t == HXR_GEOM_CSG_UNION || t == HXR_GEOM_CSG_INTER || t == HXR_GEOM_CSG_DIFF) {
+			const int below = csg_depth(d, op, level + 1);
+			if (below < 0) return below;
+			deepest = std::max(deepest, below);
+		} else if (t != HXR_GEOM_PLANE && t != HXR_GEOM_SPHERE && t != HXR_GEOM_CUBE) {
+			return -2;
+		}
+	}
+	return deepest;
+}
+
 int validate(const hxr_scene_desc* d)
 {
 	if (!d || d->abi_version != HXR_ABI_VERSION) { set_err("bad descriptor / ABI version"); return HXR_E_INVALID; }
@@ -250,19 +273,14 @@ int validate(const hxr_scene_desc* d)
 		}
 		const hxr_geometry& g = d->geometries[n.geometry];
 		if (g.type == HXR_GEOM_CSG_UNION || g.type == HXR_GEOM_CSG_INTER || g.type == HXR_GEOM_CSG_DIFF) {
-			for (int side = 0; side < 2; side++) {
-				int op = side ? g.right : g.left;
-				if (op < 0 || op >= d->num_geometries) { set_err("CSG operand outside the geometry table"); return HXR_E_INVALID; }
-				int t = d->geometries[op].type;
-				if (t != HXR_GEOM_PLANE && t != HXR_GEOM_SPHERE && t != HXR_GEOM_CUBE) {
-					// CSG over a kd-tree mesh is undefined in the reference itself: CSGBase::intersect tells the operands apart by
-					// `infoCandidate.geom == left` (src/geometry.cpp:186) and Mesh::intersectKD never sets IntersectionInfo::geom
-					// (src/mesh.cpp:247-263: only the brute-force branch does), so the comparison reads an uninitialised pointer.
-					// Nested CSG is defined there but no shipped scene uses it.  Both are refused rather than guessed at.
-					set_err("CSG (node %lld) over a mesh, heightfield or another CSG is not rendered by this build", (long long)i);
-					return HXR_E_UNSUPPORTED;
-				}
-			}
+			// operands: analytic primitives or further operations, HXR_CSG_DEPTH operations deep at most (the kernels unroll the recursion
+			// of CSGBase::intersect at compile time).  CSG over a kd-tree mesh is undefined in the reference itself: CSGBase::intersect tells
+			// the operands apart by `infoCandidate.geom == left` (src/geometry.cpp:186) and Mesh::intersectKD never sets IntersectionInfo::geom
+			// (src/mesh.cpp:247-263: only the brute-force branch does), so the comparison reads an uninitialised pointer; it is refused.
+			const int depth = csg_depth(d, n.geometry, 1);
+			if (depth == -1) { set_err("CSG operand outside the geometry table"); return HXR_E_INVALID; }
+			if (depth == -2) { set_err("CSG (node %lld) over a mesh or a heightfield is not rendered by this build", (long long)i); return HXR_E_UNSUPPORTED; }
+			if (depth > HXR_CSG_DEPTH) { set_err("CSG of node %lld is nested %d operations deep (limit %d)", (long long)i, depth, HXR_CSG_DEPTH); return HXR_E_UNSUPPORTED; }
 		}
 		if (g.type == HXR_GEOM_MESH && (g.ref < 0 || g.ref >= d->num_meshes)) { set_err("bad mesh reference"); return HXR_E_INVALID; }
 		if (g.type == HXR_GEOM_HEIGHTFIELD && (g.ref < 0 || g.ref >= d->num_heightfields)) { set_err("bad heightfield reference"); return HXR_E_INVALID; }
@@ -449,7 +467,7 @@ static_assert(HXR_SHARDS == HXR_QUEUE_SHARDS, "one sub-queue per dispenser range
 
 // Smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h); occupancy
 // target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel).
-enum Variant { V_MESH, V_MESH_REFRACT, V_HEIGHTFIELD, V_SPHERE_GI, V_MESH_GI, V_ALL_GI_3, V_ALL_GI_2, V_ALL_3, V_ALL_2 };
+enum Variant { V_MESH, V_MESH_REFRACT, V_HEIGHTFIELD, V_SPHERE_GI, V_MESH_GI, V_ALL_GI_3, V_ALL_GI_2, V_ALL_3, V_ALL_2, V_NESTED_GI, V_NESTED };
 Variant pick_variant(const hxr_scene* s)
 {
 	unsigned geom = s->features & (HXR_F_MESH | HXR_F_HEIGHTFIELD | HXR_F_SPHERE | HXR_F_CUBE | HXR_F_EXTRA);
@@ -457,6 +475,7 @@ Variant pick_variant(const hxr_scene* s)
 	const bool gi = s->settings.gi != 0, meshes = (geom & HXR_F_MESH) != 0;
 	const bool rect = (s->features & HXR_F_RECT) != 0;   // the specialised Whitted variants know PointLights only
 	const bool refr = (s->features & HXR_F_REFRACT) != 0;
+	if ((s->features & HXR_F_CSGNEST) != 0) return gi ? V_NESTED_GI : V_NESTED;   // CSG over CSG: the variants that unroll CSGBase::intersect's recursion
 	if (!gi && !rect && !refr && (geom | HXR_F_MESH) == HXR_F_MESH) return V_MESH;
 	if (!gi && !rect && (geom | HXR_F_MESH) == HXR_F_MESH) return V_MESH_REFRACT;
 	if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) return V_HEIGHTFIELD;
@@ -560,6 +579,8 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 			case V_ALL_GI_2: HXR_LAUNCH_F(HXR_F_ALL, 2); break;
 			case V_ALL_3: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3); break;
 			case V_ALL_2: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 2); break;
+			case V_NESTED_GI: HXR_LAUNCH_F(HXR_F_ALL | HXR_F_CSGNEST, 2); break;
+			case V_NESTED: HXR_LAUNCH_F((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST, 2); break;
 		}
 #undef HXR_LAUNCH_F2
 #undef HXR_LAUNCH_F
@@ -1138,7 +1159,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		else if (g.type == HXR_GEOM_HEIGHTFIELD) s->features |= HXR_F_HEIGHTFIELD;
 		else if (g.type == HXR_GEOM_SPHERE) s->features |= HXR_F_SPHERE;
 		else if (g.type == HXR_GEOM_CUBE) s->features |= HXR_F_CUBE;
-		else if (g.type >= HXR_GEOM_CSG_UNION && g.type <= HXR_GEOM_CSG_DIFF) s->features |= HXR_F_EXTRA;
+		else if (g.type >= HXR_GEOM_CSG_UNION && g.type <= HXR_GEOM_CSG_DIFF) s->features |= HXR_F_EXTRA | (csg_depth(d, n.geometry, 1) > 1 ? HXR_F_CSGNEST : 0u);
 		o.geom_type = g.type;
 		o.geom = n.geometry;
 		o.ref = g.ref;

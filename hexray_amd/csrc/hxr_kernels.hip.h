@@ -52,7 +52,12 @@ enum : unsigned {
 	// Whitted, in place: no hit of the scene spawns more than ONE secondary ray (a Layered shader with one Reflection or Refraction
 	// layer, ...), so at most one ray is ever pending per lane.  It waits in LDS (18 dwords per lane, a row per dword) instead of on
 	// the 12-entry per-lane stack, which is a dynamically indexed array and therefore lives in scratch memory.
-	HXR_F_STACK1 = 1024u
+	HXR_F_STACK1 = 1024u,
+	// CSG operations whose operands are operations (catch-all variants only).  The recursion of CSGBase::intersect is unrolled HXR_CSG_DEPTH
+	// levels deep inside two functions that are CALLED, not inlined: inlined into the flattened integrator they cost every catch-all
+	// kernel its register allocation (scratch 1 KB -> 15-29 KB per lane, kdtree_test 11.7 -> 80 ms), and as calls in the ordinary
+	// catch-alls they still cost 4x (the kernel then lives by the call ABI) -- so only scenes that nest CSG run these variants.
+	HXR_F_CSGNEST = 2048u
 };
 
 // counters (COUNT builds only); order = hxr_counters
@@ -372,9 +377,20 @@ HXR_DEV d3 analytic_normal(const hxr_geometry& G, d3 o, d3 d, const GeomHit& g, 
 }
 
 #define HXR_CSG_MAX 30   // findAllIntersections re-shoots at most 30 times per operand (src/geometry.cpp:155)
+#define HXR_CSG_DEPTH 3  // operations nested at most this deep (an operation over primitives = 1); validate() refuses deeper trees
 
-// findAllIntersections (src/geometry.cpp:149-165): distances (from the original origin) of the successive hits
-HXR_DEV int csg_collect(const hxr_geometry& G, d3 o, d3 d, double* dist)
+HXR_DEV bool is_csg(int type) { return type >= HXR_GEOM_CSG_UNION && type <= HXR_GEOM_CSG_DIFF; }
+
+// CSGBase::intersect is generic over Geometry* (src/geometry.cpp:149-194): an operand is an analytic primitive or another operation.
+// LEVEL = how many more levels of operations may still appear below (compile-time recursion: the GPU has no call stack to spare).
+template <int LEVEL>
+HXR_DEV bool csg_query(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, GeomHit& g, d3* ip_out);
+template <int LEVEL>
+HXR_DEV void csg_rehit(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v, int& prim_type);
+
+// findAllIntersections (src/geometry.cpp:149-165): distances (from the original origin) of the successive hits of operand G
+template <int LEVEL>
+HXR_DEV int csg_collect(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3 d, double* dist)
 {
 	d3 start = o;
 	int n = 0;
@@ -382,37 +398,62 @@ HXR_DEV int csg_collect(const hxr_geometry& G, d3 o, d3 d, double* dist)
 		GeomHit g;
 		g.t = HXR_INF;
 		g.tri = -1;
-		if (!analytic_query(G, start, d, g)) break;
-		d3 ip = start + d * g.t;
+		d3 ip;
+		bool nested = false;
+		if constexpr (LEVEL > 0) nested = is_csg(G.type);
+		if (nested) {
+			if constexpr (LEVEL > 0)
+				if (!csg_query<LEVEL - 1>(S, G, start, d, g, &ip)) break;   // the operand's own IntersectionInfo::ip, not start + d * dist
+		} else {
+			if (!analytic_query(G, start, d, g)) break;
+			ip = start + d * g.t;
+		}
 		dist[n++] = dist3(o, ip);
 		start = ip + d * 1e-6;
 	}
 	return n;
 }
 
-// the k-th hit of findAllIntersections again, this time with its attributes
-HXR_DEV void csg_rehit(const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v)
+// the k-th hit of findAllIntersections again, this time with its attributes (and the kind of primitive that was finally hit)
+template <int LEVEL>
+HXR_DEV void csg_rehit(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v, int& prim_type)
 {
 	d3 start = o;
 	GeomHit g;
+	bool nested = false;
+	if constexpr (LEVEL > 0) nested = is_csg(G.type);
 	for (int i = 0; i <= k; i++) {
 		g.t = HXR_INF;
 		g.tri = -1;
-		analytic_query(G, start, d, g);
-		ip = start + d * g.t;
+		if (nested) {
+			if constexpr (LEVEL > 0) csg_query<LEVEL - 1>(S, G, start, d, g, &ip);
+		} else {
+			analytic_query(G, start, d, g);
+			ip = start + d * g.t;
+		}
 		if (i < k) start = ip + d * 1e-6;
 	}
-	norm = analytic_normal(G, start, d, g, u, v);
+	if (nested) {
+		if constexpr (LEVEL > 0) {
+			csg_rehit<LEVEL - 1>(S, S.geometries[(g.tri & 1) ? G.right : G.left], start, d, g.tri >> 1, ip, norm, u, v, prim_type);
+			norm = faceforward(d, norm);   // the inner operation's own faceforward, src/geometry.cpp:187
+		}
+	} else {
+		norm = analytic_normal(G, start, d, g, u, v);
+		prim_type = G.type;
+	}
 }
 
 // CSGBase::intersect (src/geometry.cpp:167-194).  Reports the hit as g.t = distance from the origin and
 // g.tri = operand (bit 0) | ordinal of the operand's hit (bits 1..); surface_of() re-derives its attributes.
-HXR_DEV bool csg_query(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, GeomHit& g)
+// ip_out (nested use): the hit point as the chosen operand computed it.
+template <int LEVEL>
+HXR_DEV bool csg_query(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, GeomHit& g, d3* ip_out)
 {
 	const hxr_geometry& GL = S.geometries[C.left];
 	const hxr_geometry& GR = S.geometries[C.right];
 	double dl[HXR_CSG_MAX], dr[HXR_CSG_MAX];
-	int nl = csg_collect(GL, o, d, dl), nr = csg_collect(GR, o, d, dr);
+	int nl = csg_collect<LEVEL>(S, GL, o, d, dl), nr = csg_collect<LEVEL>(S, GR, o, d, dr);
 	bool inA = nl & 1, inB = nr & 1;
 	auto inside = [&](bool a, bool b) { return C.type == HXR_GEOM_CSG_UNION ? (a || b) : C.type == HXR_GEOM_CSG_INTER ? (a && b) : (a && !b); };
 	const bool initial = inside(inA, inB);
@@ -426,11 +467,40 @@ HXR_DEV bool csg_query(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, 
 		if (inside(inA, inB) != initial) {
 			g.t = take_left ? dl[il] : dr[ir];
 			g.tri = (take_left ? 0 : 1) | ((take_left ? il : ir) << 1);
+			if (ip_out) {
+				d3 n;
+				double u, v;
+				int prim;
+				csg_rehit<LEVEL>(S, take_left ? GL : GR, o, d, take_left ? il : ir, *ip_out, n, u, v, prim);
+			}
 			return true;
 		}
 		if (take_left) il++; else ir++;
 	}
 	return false;
+}
+
+// the entry points of the HXR_F_CSGNEST variants: the whole unrolled recursion behind ONE call each
+static __device__ __attribute__((noinline)) bool csg_query_nested(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, GeomHit& g)
+{
+	return csg_query<HXR_CSG_DEPTH - 1>(S, C, o, d, g, nullptr);
+}
+static __device__ __attribute__((noinline)) void csg_rehit_nested(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v, int& prim_type)
+{
+	csg_rehit<HXR_CSG_DEPTH - 1>(S, G, o, d, k, ip, norm, u, v, prim_type);
+}
+// ... and of every other variant: operands are primitives, everything inline as before
+template <unsigned F>
+HXR_DEV bool csg_query_any(const HxrSceneDev& S, const hxr_geometry& C, d3 o, d3 d, GeomHit& g)
+{
+	if constexpr ((F & HXR_F_CSGNEST) != 0) return csg_query_nested(S, C, o, d, g);
+	else return csg_query<0>(S, C, o, d, g, nullptr);
+}
+template <unsigned F>
+HXR_DEV void csg_rehit_any(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v, int& prim_type)
+{
+	if constexpr ((F & HXR_F_CSGNEST) != 0) csg_rehit_nested(S, G, o, d, k, ip, norm, u, v, prim_type);
+	else csg_rehit<0>(S, G, o, d, k, ip, norm, u, v, prim_type);
 }
 
 // Per-wave traversal stack in LDS: (node, lanes on whose behalf it is pending).
@@ -901,7 +971,7 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 		case HXR_GEOM_CSG_UNION:
 		case HXR_GEOM_CSG_INTER:
 		case HXR_GEOM_CSG_DIFF:
-			if constexpr ((F & HXR_F_EXTRA) != 0) return csg_query(S, S.geometries[N.geom], ol, dl, g);
+			if constexpr ((F & HXR_F_EXTRA) != 0) return csg_query_any<F>(S, S.geometries[N.geom], ol, dl, g);
 			return false;
 		default: return false;
 	}
@@ -917,7 +987,8 @@ HXR_DEV d3 local_hit_point(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3 
 			const hxr_geometry& C = S.geometries[N.geom];
 			d3 ip, n;
 			double u, v;
-			csg_rehit(S.geometries[(g.tri & 1) ? C.right : C.left], ol, dl, g.tri >> 1, ip, n, u, v);
+			int prim;
+			csg_rehit_any<F>(S, S.geometries[(g.tri & 1) ? C.right : C.left], ol, dl, g.tri >> 1, ip, n, u, v, prim);
 			return ip;
 		}
 	}
@@ -1068,9 +1139,10 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 			const hxr_geometry& C = S.geometries[N.geom];
 			const hxr_geometry& G = S.geometries[(g.tri & 1) ? C.right : C.left];
 			d3 hit;
-			csg_rehit(G, ol, dl, g.tri >> 1, hit, n, sf.u, sf.v);
+			int prim = 0;
+			csg_rehit_any<F>(S, G, ol, dl, g.tri >> 1, hit, n, sf.u, sf.v, prim);
 			n = faceforward(dl, n);   // src/geometry.cpp:187
-			if (G.type == HXR_GEOM_PLANE) { sf.dNdx = mk3(1, 0, 0); sf.dNdy = mk3(0, 0, 1); }
+			if (prim == HXR_GEOM_PLANE) { sf.dNdx = mk3(1, 0, 0); sf.dNdy = mk3(0, 0, 1); }
 			break;
 		}
 		default: break;

@@ -43,6 +43,12 @@
 	X(true, (HXR_F_ALL), 3)                                             \
 	X(false, (HXR_F_ALL & ~HXR_F_GI), 3)                                \
 	X(true, (HXR_F_ALL & ~HXR_F_GI), 3)
+// hxr_kernels_nested.hip: the catch-alls for scenes whose CSG operations have operations as operands (HXR_F_CSGNEST)
+#define HXR_VARIANTS_NESTED_CSG(X)                              \
+	X(false, (HXR_F_ALL | HXR_F_CSGNEST), 2)                    \
+	X(true, (HXR_F_ALL | HXR_F_CSGNEST), 2)                     \
+	X(false, ((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST), 2)      \
+	X(true, ((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST), 2)
 // hxr_kernels_heightfield.hip
 #define HXR_VARIANTS_HEIGHTFIELD(X)                  \
 	X(false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2) \

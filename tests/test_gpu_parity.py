@@ -7,12 +7,13 @@ Monte-Carlo modes use the same counter-based generator on both sides (DESIGN.md 
 are compared frame against frame with the same bar.  Full-size configs (1920x1080, BASELINE.json) are
 covered through size-independent properties: determinism, shard / tile invariance, sample accounting."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 
 import hexray_amd as hx
-from conftest import scene_path
+from conftest import ROOT, scene_path
 from oracle_binding import oracle_render
 
 pytestmark = pytest.mark.gpu
@@ -103,11 +104,38 @@ def test_camera_update_between_frames(gpu):
 
 
 def test_unsupported_scenes_fail_loudly(gpu):
-    """CSG over anything but analytic primitives is not rendered by this build: creation must fail, not fall back."""
-    nested = "CSGUnion both {\n left floor\n right c0\n}\nNode extra {\n geometry both\n shader lambert\n}\n"
-    hs = hx.HostScene(scene_path("kdtree_test.hexray"), nested)
-    with pytest.raises(hx.HipError, match="not rendered by this build"):
-        hx.DeviceScene(hs)
+    """CSG over a kd-tree mesh (undefined in the reference itself) and operations nested deeper than the kernels unroll: creation must
+    fail, not fall back."""
+    over_mesh = "CSGUnion both {\n left c0\n right teapot\n}\nNode extra {\n geometry both\n shader lambert\n}\n"
+    with pytest.raises(hx.HipError, match="over a mesh or a heightfield is not rendered by this build"):
+        hx.DeviceScene(hx.HostScene(scene_path("kdtree_test.hexray"), over_mesh))
+    deep = ("CSGUnion d2 {\n left floor\n right c0\n}\nCSGInter d3 {\n left d2\n right c1\n}\nCSGDiff d4 {\n left d3\n right c0\n}\n"
+            "Node extra {\n geometry d4\n shader lambert\n}\n")
+    with pytest.raises(hx.HipError, match="nested 4 operations deep"):
+        hx.DeviceScene(hx.HostScene(scene_path("kdtree_test.hexray"), deep))
+
+
+def test_nested_csg_matches_oracle(gpu):
+    """Operations whose operands are operations (CSGBase::intersect is generic over Geometry*): a die three operations deep and a lens
+    on a stand, Whitted with reflections and 4-sample Monte-Carlo.  The oracle's nested CSG is pinned to the reference by 576 vectors."""
+    scene = os.path.join(ROOT, "tests", "golden", "nested_csg.hexray")
+    for ov in ("", hx.overlay_text(200, 150, dof=True, num_samples=4)):
+        hs = hx.HostScene(scene, ov)
+        ds = hx.DeviceScene(hs)
+        p = hx.frame_params(collect_counters=True)
+        g = ds.render(p)
+        gc = ds.counters()
+        o, oc = oracle_render(hs, p)
+        assert np.all(rms(g, o) <= RMS_BAR), rms(g, o)
+        for k in ("camera_samples", "raycasts", "shadow_queries", "node_tests"):
+            assert gc[k] == oc[k], (k, gc[k], oc[k])
+        ds.close()
+    # two operations deep over the shipped scene: the refused case of earlier rounds
+    nested = "CSGUnion both {\n left floor\n right c0\n}\nNode extra {\n geometry both\n shader lambert\n translate (150, -60, 120)\n scale (0.3, 0.3, 0.3)\n}\n"
+    hs = hx.HostScene(scene_path("kdtree_test.hexray"), hx.overlay_text(160, 120) + nested)
+    g = hx.DeviceScene(hs).render()
+    o, _ = oracle_render(hs)
+    assert np.all(rms(g, o) <= RMS_BAR), rms(g, o)
 
 
 # element classes outside the five configs (SURVEY.md section 8f rank 4): Cube + CSG, glossy Reflection, autofocus,

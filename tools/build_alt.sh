@@ -13,8 +13,10 @@ hipcc $HIPFLAGS -O2 -c -o build/alt_$tag/hf.o hexray_amd/csrc/hxr_kernels_height
 p2=$!
 hipcc $HIPFLAGS $MESH_FLAGS -c -o build/alt_$tag/mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
 p3=$!
+hipcc $HIPFLAGS -O2 -c -o build/alt_$tag/nested.o hexray_amd/csrc/hxr_kernels_nested.hip &
+p4=$!
 hipcc $HIPFLAGS -O3 -c -o build/alt_$tag/kd.o hexray_amd/csrc/hxr_kd_build.hip
 hipcc $HIPFLAGS -O3 -c -o build/alt_$tag/api.o hexray_amd/csrc/hxr_api.hip
-wait $p1; wait $p2; wait $p3
-hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip_$tag.so build/alt_$tag/api.o build/alt_$tag/kd.o build/alt_$tag/mesh.o build/alt_$tag/mesh2.o build/alt_$tag/hf.o
+wait $p1; wait $p2; wait $p3; wait $p4
+hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip_$tag.so build/alt_$tag/api.o build/alt_$tag/kd.o build/alt_$tag/mesh.o build/alt_$tag/mesh2.o build/alt_$tag/hf.o build/alt_$tag/nested.o
 echo built hexray_amd/lib/libhexray_hip_$tag.so
