@@ -88,17 +88,32 @@ HXR_DEV d3 cross(d3 a, d3 b) { return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x 
 HXR_DEV double len(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 HXR_DEV double len2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 HXR_DEV d3 unit(d3 a) { return a * (1.0 / len(a)); }                       // Vector::normalize, src/vector.h:79-83
-HXR_DEV d3 unit_lazy(d3 a)                                                 // normalize(), src/vector.h:160-165
+// normalize(), src/vector.h:160-165: `l = length(a); if (fabs(l - 1) < 1e-6) return a; return a * (1 / l);`
+// ON_SQUARE decides it on l^2 -- (1 - 1e-6)^2 < l^2 < (1 + 1e-6)^2 is the same interval -- and pays for the square root and the division
+// only when some lane of the wave leaves it.  Every ray direction through a rotation-only or translate-only node lands inside (smallpt's
+// nodes never take the slow path: -1.7 %); where nodes scale (the meshes of meshes.hexray) the extra test and ballot are pure cost
+// (+1.8 % on the headline frame), so the variants choose (fast_transforms).
+template <bool ON_SQUARE = false>
+HXR_DEV d3 unit_lazy(d3 a)
 {
-	// `if (fabs(l - 1) < 1e-6) return a;` decided on l^2: (1 - 1e-6)^2 < l^2 < (1 + 1e-6)^2 is the same interval, and the square
-	// root and the division are only paid for when some lane of the wave leaves it (rays through a node with a scaling transform).
-	// Every ray direction and every rotation-only transform lands inside: smallpt's seven nodes never take the slow path.
-	const double l2 = len2(a);
-	const bool keep = l2 > 0.999998000001 && l2 < 1.000002000001;
-	if (!hxr_ballot(!keep)) return a;
-	const double l = sqrt(l2);
-	return keep ? a : a * (1 / l);
+	if constexpr (ON_SQUARE) {
+		const double l2 = len2(a);
+		const bool keep = l2 > 0.999998000001 && l2 < 1.000002000001;
+		if (!hxr_ballot(!keep)) return a;
+		const double l = sqrt(l2);
+		return keep ? a : a * (1 / l);
+	} else {
+		const double l = len(a);
+		if (fabs(l - 1.0) < 1e-6) return a;
+		return a * (1 / l);
+	}
 }
+// The path tracers and the variants without kd meshes take the two shortcuts of Node::intersect's transforms -- unit_lazy on the square,
+// and no matrix products for translate-only nodes (mul_identity) -- which pay where most nodes are unscaled spheres and planes (smallpt
+// -2 % and -1.7 %, heightfield -1.7 %, cornell box -2.4 %) and cost the Whitted mesh kernels 3 % + 1.8 % in registers and branches even
+// when no node of the scene qualifies (measured against the builds before / after each, on one box: 8.85 -> 8.99 -> 9.28 ms).
+template <unsigned F>
+constexpr bool fast_transforms = (F & HXR_F_MESH) == 0 || (F & HXR_F_GI) != 0;
 HXR_DEV double dist3(d3 a, d3 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z)); }
 HXR_DEV d3 faceforward(d3 ray, d3 n) { return dot(ray, n) < 0 ? n : -n; }  // src/vector.h:179-182
 HXR_DEV d3 reflect3(d3 i, d3 n) { return n * (2 * dot(-i, n)) + i; }       // src/vector.h:184-187
@@ -1036,16 +1051,17 @@ HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, double reach_l
 		}
 	}
 	d3 ol, dl;
-	if (N.identity) {   // wave-uniform: the matrices of this node are exactly the identity
+	const bool identity = fast_transforms<F> && N.identity;   // wave-uniform: the matrices of this node are exactly the identity
+	if (identity) {
 		ol = mul_identity(o - ld3(N.T.offset));
-		dl = unit_lazy(mul_identity(d));
+		dl = unit_lazy<fast_transforms<F>>(mul_identity(d));
 	} else {
 		ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
-		dl = unit_lazy(mulm(d, N.T.inv_m));
+		dl = unit_lazy<fast_transforms<F>>(mulm(d, N.T.inv_m));
 	}
 	if (!geometry_query<COUNT, F>(S, N, ol, dl, g, st, tl)) return false;
 	const d3 lp = local_hit_point<F>(S, N, ol, dl, g);
-	d3 ipw = (N.identity ? mul_identity(lp) : mulm(lp, N.T.m)) + ld3(N.T.offset);
+	d3 ipw = (identity ? mul_identity(lp) : mulm(lp, N.T.m)) + ld3(N.T.offset);
 	wdist = dist3(o, ipw);
 	return true;
 }
@@ -1062,12 +1078,13 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 {
 	const HxrNodeDev& N = S.nodes[ni];
 	d3 ol, dl;
-	if (N.identity) {
+	const bool identity = fast_transforms<F> && N.identity;
+	if (identity) {
 		ol = mul_identity(o - ld3(N.T.offset));
-		dl = unit_lazy(mul_identity(d));
+		dl = unit_lazy<fast_transforms<F>>(mul_identity(d));
 	} else {
 		ol = mulm(o - ld3(N.T.offset), N.T.inv_m);
-		dl = unit_lazy(mulm(d, N.T.inv_m));
+		dl = unit_lazy<fast_transforms<F>>(mulm(d, N.T.inv_m));
 	}
 	d3 ip = local_hit_point<F>(S, N, ol, dl, g);
 	d3 n = mk3(0, 0, 0);
@@ -1147,8 +1164,8 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 		}
 		default: break;
 	}
-	sf.ip = (N.identity ? mul_identity(ip) : mulm(ip, N.T.m)) + ld3(N.T.offset);
-	sf.norm = unit(N.identity ? mul_identity(n) : mulm(n, N.T.tinv_m));
+	sf.ip = (identity ? mul_identity(ip) : mulm(ip, N.T.m)) + ld3(N.T.offset);
+	sf.norm = unit(identity ? mul_identity(n) : mulm(n, N.T.tinv_m));
 	sf.dist = wdist;
 }
 
@@ -1885,6 +1902,7 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 // ------------------------------------------------------------------------------------------------
 // camera (Camera::getScreenRay src/camera.cpp:65-76, getDOFScreenRay :78-86) and traceSingleRay (src/main.cpp:227-249)
 // ------------------------------------------------------------------------------------------------
+template <bool ON_SQUARE>
 HXR_DEV void camera_ray(const HxrSceneDev& S, int W, int H, double x, double y, double lu, double lv, double stereo, d3& o, d3& d)
 {
 	const hxr_camera& c = S.camera;
@@ -1897,7 +1915,7 @@ HXR_DEV void camera_ray(const HxrSceneDev& S, int W, int H, double x, double y, 
 		double M = c.focal_plane_dist / dot(ld3(c.front), d);
 		d3 T = o + d * M;
 		o = pos + ld3(c.right) * (lu * c.aperture_size) + ld3(c.up) * (lv * c.aperture_size);
-		d = unit_lazy(T - o);
+		d = unit_lazy<ON_SQUARE>(T - o);
 	}
 }
 
@@ -1919,7 +1937,7 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	// the anaglyph pair is compiled into the catch-all variants only (the launcher sends stereo cameras there): a second
 	// inlined copy of the integrator doubles the code of the specialised kernels for a mode none of the config scenes uses
 	if ((F & HXR_F_EXTRA) == 0 || S.camera.stereo_separation == 0.0) {
-		camera_ray(S, W, H, x, y, lu, lv, 0, o, d);
+		camera_ray<(F & HXR_F_GI) != 0>(S, W, H, x, y, lu, lv, 0, o, d);
 		tl.template lap<PH_GEN>();
 		f3 c = trace_rays<COUNT, F>(S, RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u}, rc, st, tl, dq);
 		tl.template lap<PH_SHADE>();
@@ -1927,7 +1945,7 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	}
 	f3 eye[2];
 	for (int e = 0; e < 2; e++) {   // anaglyph pair (src/main.cpp:237-247)
-		camera_ray(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
+		camera_ray<(F & HXR_F_GI) != 0>(S, W, H, x, y, lu, lv, e == 0 ? -0.5 : +0.5, o, d);
 		eye[e] = trace_rays<COUNT, F>(S, RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u}, rc, st, tl, dq);
 	}
 	float ml = intensity(eye[0]), mr = intensity(eye[1]);
