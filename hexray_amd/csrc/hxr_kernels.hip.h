@@ -1035,7 +1035,7 @@ HXR_DEV bool node_query(const HxrSceneDev& S, int ni, d3 o, d3 d, double reach_l
 			far_side = (sA > eps && sB > eb) || (sA < -eps && sB < -eb);
 		}
 		if (!hxr_ballot(!(away || far_side))) return false;
-	} else if (N.cullable) {
+	} else if (N.cullable == 1) {
 		// World-space rejection: when NO ray of the wave reaches the node's (inflated) world box, the reference's
 		// Node::intersect would return false for every one of them -- after transforming the ray and, for a mesh,
 		// failing the root BBox::testIntersect (src/mesh.cpp:249), which is counted as if it had been made.
