@@ -565,12 +565,12 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 			case V_MESH:
 				if (defer) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_DEFER, HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
 				else if (one_pending) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_STACK1, HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
-				else HXR_LAUNCH_F2(HXR_F_MESH, HXR_F_MESH | HXR_F_REFRACT, 3);
+				else HXR_LAUNCH_F2(HXR_F_MESH, HXR_F_MESH | HXR_F_REFRACT, HXR_MESH_WAVES);
 				break;
 			case V_MESH_REFRACT:
 				if (defer) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
 				else if (one_pending) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
-				else HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, 3);
+				else HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, HXR_MESH_WAVES);
 				break;
 			case V_HEIGHTFIELD: HXR_LAUNCH_F(HXR_F_HEIGHTFIELD | HXR_F_REFRACT, 2); break;
 			case V_SPHERE_GI: HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, 2); break;

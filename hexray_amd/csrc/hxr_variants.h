@@ -17,10 +17,13 @@
 	X(true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER), 3)
 // ... and the same integrator tracing secondary rays in place: the continuation pass runs these (hxr_continue_kernel), and so
 // do frames whose ray queue would not fit (hxr_api.hip, plan_defer)
+#ifndef HXR_MESH_WAVES
+#define HXR_MESH_WAVES 3   // waves per SIMD the in-place Whitted mesh kernels are compiled for (re-measured at the end of round 2: 8.9 ms at 3, 10.45 ms at 2)
+#endif
 #define HXR_VARIANTS_MESH_INPLACE(X)          \
-	X(false, (HXR_F_MESH), 3)                 \
-	X(false, (HXR_F_MESH | HXR_F_REFRACT), 3) \
-	X(true, (HXR_F_MESH | HXR_F_REFRACT), 3)
+	X(false, (HXR_F_MESH), HXR_MESH_WAVES)                 \
+	X(false, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES) \
+	X(true, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES)
 // ... with at most one secondary ray pending per lane (no Layered shader of the scene has two Reflection / Refraction layers): the
 // default for mesh scenes -- the per-lane ray stack leaves scratch memory
 #define HXR_VARIANTS_MESH_STACK1(X)                              \
