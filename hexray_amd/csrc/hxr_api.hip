@@ -248,7 +248,7 @@ int validate(const hxr_scene_desc* d)
 		const bool tables = h.first_maxh >= 0 && h.first_highmap >= 0;
 		const bool normals_ok = h.raw_heights ? true : (h.first_normal >= 0 && h.first_normal <= d->f64_pool_size / 3 && cells <= d->f64_pool_size / 3 - h.first_normal);
 		const bool raw_ok = !h.raw_heights || (!tables && h.blur_radius >= 0 && h.blur_radius <= 128 && (h.blur_radius == 0 || floats_ok(h.first_blur_kernel, (int64_t)h.blur_radius * h.blur_radius)));
-		if (h.W <= 0 || h.H <= 0 || cells > (1ll << 30) || !floats_ok(h.first_height, cells) || (tables && (!floats_ok(h.first_maxh, cells) || !floats_ok(h.first_highmap, cells * 16))) ||
+		if (h.W <= 0 || h.H <= 0 || cells > (1ll << 30) || !floats_ok(h.first_height, cells) || (tables && (!floats_ok(h.first_maxh, cells) || (h.use_optimization && !floats_ok(h.first_highmap, cells * 16)))) ||
 		    h.max_k < 0 || h.max_k > 16 || !normals_ok || !raw_ok) {
 			set_err("heightfield %lld: a table range lies outside the descriptor", (long long)i);
 			return HXR_E_INVALID;

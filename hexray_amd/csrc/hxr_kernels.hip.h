@@ -1645,8 +1645,12 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 					} else {     // explicit light sampling of the path tracer (src/main.cpp:157-168)
 						d3 w_out = unit(lp - hp.ip);
 						f3 ev = mkf(1, 0, 0);   // BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
-						if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG)
+						if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG) {
+							// the reference samples the texture once in spawnRay and again here; the value is the same, so the kernel kept it
+							// (`base`) and only the work counter notes the second bilinear lookup
+							if (COUNT && sh.texture >= 0 && S.textures[sh.texture].type == HXR_TEX_BITMAP) tl.add(HC_TEX);
 							ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, hp.norm));
+						}
 						else if (sh.type == HXR_SHADER_REFLECTION)
 							ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
 						else if (sh.type == HXR_SHADER_REFRACTION)

@@ -750,7 +750,10 @@ static int raycast(ctx_t* cx, const ray_t* ray, hit_t* best, int* best_node, col
 	best->dist = HXO_INF;
 	*best_node = -1;
 	for (int64_t i = 0; i < sc->num_nodes; i++) {
+		/* The reference's `IntersectionInfo info;` is uninitialised here (Vector() {} writes nothing), and Sphere / Cube / CSG never set
+		   dNdx / dNdy: a bump map on such a node reads stack garbage there.  This restatement (and the kernels) define them as zero. */
 		hit_t h;
+		memset(&h, 0, sizeof h);
 		if (node_hit(cx, (int)i, ray, &h) && h.dist < best->dist) {
 			*best = h;
 			*best_node = (int)i;
