@@ -130,3 +130,50 @@ def test_random_scene_matches_oracle(gpu, tmp_path, seed):
     for k in ("raycasts", "shadow_queries", "node_tests", "bbox_tests", "kd_visits", "tri_tests", "tex_bilinear", "env_bilinear", "hf_calls", "hf_tri_tests"):
         assert abs(gc[k] - oc[k]) <= max(8, oc[k] // 1000), (seed, mode, k, gc[k], oc[k])
     ds.close()
+
+
+@pytest.mark.parametrize("seed", range(2, 26, 2))
+def test_random_scene_through_the_other_entry_points(gpu, tmp_path, seed):
+    """The same generated scenes through what else the ABI offers, each against the plain frame: three shards assembled on the GPU, an
+    odd tile size, a repeated frame (the adaptive schedule at work), deferred secondary rays, a scene whose kd-trees / heightfield tables
+    were prepared by the module, a device group of two handles on the one GPU."""
+    import torch
+    from hexray_amd.distributed import padded_tiles_per_rank
+    geom = os.path.relpath(os.path.join(ROOT, "data", "geom"), tmp_path)
+    text, mode = make_scene(seed, geom)
+    path = os.path.join(tmp_path, "fuzz_%d.hexray" % seed)
+    with open(path, "w") as f:
+        f.write(text)
+    hs = hx.HostScene(path)
+    ds = hx.DeviceScene(hs)
+    W, H = hs.settings.frame_width, hs.settings.frame_height
+    base = ds.render(hx.frame_params())
+    assert np.array_equal(ds.render(hx.frame_params()), base)                     # scheduled from the first frame's cost map
+    assert np.array_equal(ds.render(hx.frame_params(tile_size=24)), base)        # packets in another order
+    if mode != "aa":   # (sharded adaptive AA is covered by tests/test_gpu_parity.py: it needs the halo exchange set up there)
+        world, tile = 3, 16
+        slots = padded_tiles_per_rank(W, H, tile, world)
+        parts = []
+        for rank in range(world):
+            p = hx.frame_params(tile_size=tile, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
+            buf = torch.zeros(slots * tile * tile * 3, dtype=torch.float32, device="cuda")
+            ds.render_device(p, buf.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+            parts.append(buf)
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        p0 = hx.frame_params(tile_size=tile, shard_rank=0, shard_count=world, layout=hx.LAYOUT_TILES)
+        ds.assemble_frame(p0, torch.cat(parts).data_ptr(), slots * tile * tile * 12, frame.data_ptr(), W * 12, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), base)
+
+    def close(a, b=base):
+        return np.sqrt(np.mean((a.astype(np.float64) - b) ** 2, axis=(0, 1))).max() <= 1e-4
+
+    assert close(hx.DeviceScene(hs, deferred_rays=True).render(hx.frame_params()))           # another summation order at most
+    bare = hx.HostScene(path, gpu_kd_build=True, gpu_heightfield_tables=True)
+    assert np.array_equal(hx.DeviceScene(bare, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD).render(hx.frame_params()), base)
+    assert close(hx.DeviceScene(hs, accel=hx.ACCEL_SAH).render(hx.frame_params()))
+    raw = hx.HostScene(path, gpu_heightfield_blur=True, gpu_prepare_triangles=True, gpu_kd_build=True)
+    assert close(hx.DeviceScene(raw, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD, device_prepare_triangles=True).render(hx.frame_params()))
+    group = hx.DeviceGroup(hs, [0, 0])
+    assert np.array_equal(group.render(hx.frame_params()), base)
+    group.close()
