@@ -32,7 +32,8 @@ def make_scene(seed, geom_dir=None, without=()):
              % (col(r, 0.05, 0.3), "on" if mode == "aa" else "off", r.randint(2, 5), "\tgi on\n\tnumPaths 3\n" if mode == "gi" else ""))
     t.append("Camera camera {\n\tpos (%.3f, %.3f, %.3f)\n\taspectRatio 1.33333\n\tyaw %.2f\n\tpitch %.2f\n\troll %.2f\n\tfov %.1f\n%s}\n"
              % (r.uniform(-8, 8), r.uniform(10, 30), r.uniform(-60, -40), r.uniform(-10, 10), r.uniform(-25, -5), r.uniform(-5, 5), r.uniform(50, 90),
-                "\tdof on\n\tfNumber %.1f\n\tfocalPlaneDist %.2f\n\tnumSamples 3\n" % (r.uniform(2, 8), r.uniform(40, 60)) if mode == "dof" else ""))
+                ("\tdof on\n\tfNumber %.1f\n\tfocalPlaneDist %.2f\n\tnumSamples 3\n%s" % (r.uniform(2, 8), r.uniform(40, 60), "\tautoFocus on\n" if seed % 8 == 6 else "") if mode == "dof" else "")
+                + ("\tstereoSeparation %.2f\n" % r.uniform(0.5, 3) if seed % 7 == 3 else "")))
     for i in range(r.randint(1, 2)):
         t.append("PointLight pl%d {\n\tpos (%.2f, %.2f, %.2f)\n\tpower %.0f\n\tcolor %s\n}\n" % (i, r.uniform(-60, 60), r.uniform(50, 120), r.uniform(-80, 20), r.uniform(15000, 60000), col(r, 0.5, 1)))
     if mode == "gi" or r.random() < 0.3:
@@ -177,3 +178,24 @@ def test_random_scene_through_the_other_entry_points(gpu, tmp_path, seed):
     group = hx.DeviceGroup(hs, [0, 0])
     assert np.array_equal(group.render(hx.frame_params()), base)
     group.close()
+
+
+@pytest.mark.parametrize("seed", (0, 4, 8, 12, 16, 20))
+def test_random_scene_other_render_modes(gpu, tmp_path, seed):
+    """Generated Whitted scenes through the modes render() does not pick by itself: pass 1 alone, the coarse prepass, foveated pass 1 and
+    foveated adaptive AA -- against the oracle's restatements of the same loops."""
+    text, mode = make_scene(seed, os.path.relpath(os.path.join(ROOT, "data", "geom"), tmp_path))
+    assert mode == "whitted"
+    path = os.path.join(tmp_path, "fuzz_%d.hexray" % seed)
+    with open(path, "w") as f:
+        f.write(text)
+    hs = hx.HostScene(path)
+    ds = hx.DeviceScene(hs)
+    for fp in (dict(mode=hx.MODE_SINGLE), dict(mode=hx.MODE_PREPASS, spp=3), dict(mode=hx.MODE_SINGLE, foveated_radius=18, vip=(30, 25)),
+               dict(mode=hx.MODE_ADAPTIVE_AA, foveated_radius=22, vip=(50, 30)), dict(mode=hx.MODE_MONTE_CARLO, spp=5), dict(mode=hx.MODE_ADAPTIVE_AA)):
+        got = ds.render(hx.frame_params(collect_counters=True, **fp))
+        gc = ds.counters()
+        want, oc = oracle_render(hs, hx.frame_params(**fp))
+        rms = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2, axis=(0, 1)))
+        assert rms.max() <= 1e-4, (seed, fp, rms)
+        assert gc["camera_samples"] == oc["camera_samples"] and abs(gc["raycasts"] - oc["raycasts"]) <= 8, (seed, fp, gc["raycasts"], oc["raycasts"])
