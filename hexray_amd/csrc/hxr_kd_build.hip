@@ -5,15 +5,15 @@
 // BBox::intersectTriangle of every triangle of its list against both halves (one triangle per lane) and writes the two
 // child lists with a workgroup-wide stable partition (ballot + popcount ranks), so every list keeps the order the
 // reference's push_back loop gives it (src/mesh.cpp:108-116).  Child tasks, child node pairs, list space and leaf space
-// are claimed with one atomicAdd each; the host reads the task count back after each level (it sizes the next launch and
-// sees the end of the build and any capacity overflow, which restarts the build with larger buffers).  The atomics make
+// are claimed with one atomicAdd each; levels are launched back to back (a level reads its own task count), and the host looks
+// at the control words every eight levels to see the end of the build and any capacity overflow, which restarts the build with larger buffers.  The atomics make
 // the device-side numbering of nodes and leaf lists vary from run to run; the copy back renumbers the tree in the host
 // builder's order (pre-order child pairs, depth-first leaf lists), which makes the result deterministic and directly
 // comparable with a host-built tree.
 //
 // Scope: the work of a task is not split across workgroups, so the first levels of a mesh (few tasks, long lists) run on
-// a few CUs -- 36 rounds of 256 triangles for the root of the 9120-triangle teapot.  For the reference's meshes the whole
-// build is a few hundred microseconds of device time plus one ~10-20 us hand-shake per level.
+// a few CUs -- 9 rounds of 1024 triangles for the root of the 9120-triangle teapot.  For the reference's meshes the whole
+// build is a few hundred microseconds of device time plus a few microseconds of launch per level.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -25,7 +25,6 @@
 namespace hxr_kd {
 namespace {
 
-#define KD_BLOCK 256
 #define KD_LEAF_BELOW 20   // TRIANGLES_PER_LEAF, src/mesh.cpp:97
 #define KD_MAX_DEPTH 64    // MAX_TREE_DEPTH, src/mesh.cpp:97 (a node deeper than this is a leaf)
 
@@ -130,14 +129,16 @@ __global__ void kd_iota_kernel(int32_t* list, uint32_t n)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) list[i] = (int32_t)i;
 }
 
+template <int KD_BLOCK>
 __global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, const KdTask* __restrict__ tasks_in,
-                                                            uint32_t n_in, const int32_t* __restrict__ list_in, KdTask* __restrict__ tasks_out,
+                                                            int side_in, const int32_t* __restrict__ list_in, KdTask* __restrict__ tasks_out,
                                                             int32_t* __restrict__ list_out, hxr_kd_node* __restrict__ nodes, int32_t* __restrict__ leaf_idx,
                                                             KdCtl* __restrict__ ctl, int side_out, KdCaps caps)
 {
 	__shared__ uint32_t s_claim[4];               // leaf: {first}; split: {list base, first child node, task slot}; [3] = 1 when a capacity ran out
 	__shared__ uint32_t s_left[KD_BLOCK / 64], s_right[KD_BLOCK / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t n_in = ctl->side[side_in][0];   // written by the previous level (stream order): the host does not have to know it
 	for (uint32_t ti = blockIdx.x; ti < n_in; ti += gridDim.x) {
 		const KdTask T = tasks_in[ti];
 		const uint32_t count = (uint32_t)T.count;
@@ -341,20 +342,32 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 	KD_TRY(hipMemcpy(B.ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
 	if (n) hipLaunchKernelGGL(kd_iota_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, nullptr, B.lists[0], n);
 
-	uint32_t n_in = 1;
+	// Levels are launched back to back with a fixed grid (a level reads its task count on the device); the host looks at the control
+	// words only every KD_LEVELS_PER_LOOK levels, to see the end of the build or a capacity overflow.  Launching a level that turns out
+	// empty costs a few microseconds, a look ~20.
+	enum { KD_LEVELS_PER_LOOK = 8, KD_GRID = 2048, KD_WIDE_LEVELS = 8 };
 	int side_in = 0, levels = 0;
-	while (n_in > 0) {
-		const int side_out = side_in ^ 1;
-		KD_TRY(hipMemsetAsync(&B.ctl->side[side_out][0], 0, 2 * sizeof(uint32_t), nullptr));
-		hipLaunchKernelGGL(kd_level_kernel, dim3(n_in < 4096 ? n_in : 4096), dim3(KD_BLOCK), 0, nullptr, d_tris, d_verts, B.tasks[side_in], n_in, B.lists[side_in],
-		                   B.tasks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps);
+	bool done = false;
+	while (!done) {
+		for (int k = 0; k < KD_LEVELS_PER_LOOK; k++) {
+			const int side_out = side_in ^ 1;
+			KD_TRY(hipMemsetAsync(&B.ctl->side[side_out][0], 0, 2 * sizeof(uint32_t), nullptr));
+			// the first levels are few tasks with long lists: 1024 lanes per task there (the root of a 120 000-triangle mesh: 118 rounds
+			// instead of 469), 256 where the tasks are many and short
+			if (levels < KD_WIDE_LEVELS)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_level_kernel<1024>), dim3(KD_GRID / 4), dim3(1024), 0, nullptr, d_tris, d_verts, B.tasks[side_in], side_in, B.lists[side_in],
+				                   B.tasks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_level_kernel<256>), dim3(KD_GRID), dim3(256), 0, nullptr, d_tris, d_verts, B.tasks[side_in], side_in, B.lists[side_in],
+				                   B.tasks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps);
+			side_in = side_out;
+			levels++;
+		}
 		KD_TRY(hipGetLastError());
-		KD_TRY(hipMemcpy(&ctl, B.ctl, sizeof ctl, hipMemcpyDeviceToHost));   // the per-level hand-shake (synchronises)
-		levels++;
+		KD_TRY(hipMemcpy(&ctl, B.ctl, sizeof ctl, hipMemcpyDeviceToHost));   // the look (synchronises)
 		if (ctl.error) { *overflow = true; return 0; }
-		n_in = ctl.side[side_out][0];
-		side_in = side_out;
-		if (levels > KD_MAX_DEPTH + 2) { say(err, err_len, "kd build did not terminate"); return HXR_E_INVALID; }
+		done = ctl.side[side_in][0] == 0;
+		if (levels > KD_MAX_DEPTH + 2 * KD_LEVELS_PER_LOOK) { say(err, err_len, "kd build did not terminate"); return HXR_E_INVALID; }
 	}
 	out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	out.levels = levels;
