@@ -287,19 +287,29 @@ void say(char* err, size_t n, const char* fmt, ...)
 	va_end(ap);
 }
 
-struct DeviceBuffers {
+struct DeviceBuffers {   // ONE allocation, sliced (a hipMalloc / hipFree pair costs more than a level of the build)
+	void* block = nullptr;
 	KdTask* tasks[2] = {nullptr, nullptr};
 	int32_t* lists[2] = {nullptr, nullptr};
 	hxr_kd_node* nodes = nullptr;
 	int32_t* leaf = nullptr;
 	KdCtl* ctl = nullptr;
-	~DeviceBuffers()
+	hipError_t allocate(const KdCaps& caps)
 	{
-		for (int i = 0; i < 2; i++) { if (tasks[i]) (void)hipFree(tasks[i]); if (lists[i]) (void)hipFree(lists[i]); }
-		if (nodes) (void)hipFree(nodes);
-		if (leaf) (void)hipFree(leaf);
-		if (ctl) (void)hipFree(ctl);
+		auto round = [](size_t n) { return (n + 255) & ~(size_t)255; };
+		const size_t s_tasks = round((size_t)caps.tasks * sizeof(KdTask)), s_list = round((size_t)caps.list * sizeof(int32_t)),
+		             s_nodes = round((size_t)caps.nodes * sizeof(hxr_kd_node)), s_leaf = round((size_t)caps.leaf * sizeof(int32_t)), s_ctl = round(sizeof(KdCtl));
+		const hipError_t e = hipMalloc(&block, 2 * s_tasks + 2 * s_list + s_nodes + s_leaf + s_ctl);
+		if (e != hipSuccess) return e;
+		char* at = (char*)block;
+		for (int i = 0; i < 2; i++) { tasks[i] = (KdTask*)at; at += s_tasks; }
+		for (int i = 0; i < 2; i++) { lists[i] = (int32_t*)at; at += s_list; }
+		nodes = (hxr_kd_node*)at; at += s_nodes;
+		leaf = (int32_t*)at; at += s_leaf;
+		ctl = (KdCtl*)at;
+		return hipSuccess;
 	}
+	~DeviceBuffers() { if (block) (void)hipFree(block); }
 };
 
 #define KD_TRY(expr)                                                                                           \
@@ -317,13 +327,7 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 {
 	*overflow = false;
 	DeviceBuffers B;
-	for (int i = 0; i < 2; i++) {
-		KD_TRY(hipMalloc((void**)&B.tasks[i], (size_t)caps.tasks * sizeof(KdTask)));
-		KD_TRY(hipMalloc((void**)&B.lists[i], (size_t)caps.list * sizeof(int32_t)));
-	}
-	KD_TRY(hipMalloc((void**)&B.nodes, (size_t)caps.nodes * sizeof(hxr_kd_node)));
-	KD_TRY(hipMalloc((void**)&B.leaf, (size_t)caps.leaf * sizeof(int32_t)));
-	KD_TRY(hipMalloc((void**)&B.ctl, sizeof(KdCtl)));
+	KD_TRY(B.allocate(caps));
 
 	const auto t0 = std::chrono::steady_clock::now();
 	KdTask root;

@@ -15,3 +15,14 @@ for name in (sys.argv[1:] or ["meshes.hexray", "heightfield.hexray", "simple.hex
         t3 = time.perf_counter()
         print(name, "host %.1f ms, hxr_scene_create %.1f ms, with SAH rebuild %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3), flush=True)
         ds.close(); ds2.close()
+
+# ... and with the kd-trees (and a heightfield's blur / normals / pyramid) left to the module
+for name in ("meshes.hexray", "heightfield.hexray"):
+    for rep in range(3):
+        t0 = time.perf_counter()
+        bare = hx.HostScene(os.path.join(ROOT, "data", name), gpu_kd_build=True, gpu_heightfield_blur=True)
+        t1 = time.perf_counter()
+        ds = hx.DeviceScene(bare, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD)
+        t2 = time.perf_counter()
+        print("%s prepared on the GPU: host %.1f ms, hxr_scene_create %.1f ms" % (name, (t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+        ds.close()
