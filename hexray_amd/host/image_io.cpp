@@ -122,13 +122,30 @@ static float srgb_to_linear(float x)   // decompress_sRGB (src/color.h:49-57)
 	return powf((x + 0.055f) / 1.055f, 2.4f);
 }
 
-void decode_gamma(Image& img, float gamma)
+// Bitmap::decompressGamma (src/bitmap.cpp:321-338) over a span of channel values
+static void decode_span(float* p, size_t n, bool srgb, float gamma)
 {
-	bool srgb = fabsf(gamma - 2.2f) < 1e-6f;
-	for (float& c : img.rgb) {
+	for (size_t i = 0; i < n; i++) {
+		float& c = p[i];
 		if (!(c > 0)) continue;
 		c = srgb ? srgb_to_linear(c) : powf(c, gamma);
 	}
+}
+
+void decode_gamma(Image& img, float gamma)
+{
+	const bool srgb = fabsf(gamma - 2.2f) < 1e-6f;
+	// The texels of an 8-bit image are one of 256 values (q / 255.0f): decode each once, through the same loop (this build's -ffast-math
+	// lets the compiler vectorise powf, whose lanes round like each other but not like the scalar function: going through the one loop
+	// keeps every texel what the straight pass gave it).  An image with any other value (an EXR source) takes the straight pass.
+	float key[256], val[256];
+	for (int q = 0; q < 256; q++) key[q] = val[q] = q / 255.0f;
+	for (float c : img.rgb) {
+		const int q = (int)(c * 255.0f + 0.5f);
+		if (!(q >= 0 && q < 256 && key[q] == c)) { decode_span(img.rgb.data(), img.rgb.size(), srgb, gamma); return; }
+	}
+	decode_span(val, 256, srgb, gamma);
+	for (float& c : img.rgb) c = val[(int)(c * 255.0f + 0.5f)];
 }
 
 void differentiate(Image& img)
