@@ -1527,20 +1527,20 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 				d3 bu = unit(cross(tv, e.n));
 				d3 bv = cross(bu, e.n);
 				d3 refl = e.n;
-				for (uint32_t attempt = 0;; attempt++) {   // `do { ... } while (dot(reflected, n) < 0)`, bounded
+				for (uint32_t attempt = 0;; attempt++) {   // `do { ... } while (dot(reflected, n) < 0)`, bounded: 16 turns, as the oracle (both loops are unbounded in the reference; a disk draw fails 16 times in a row with p = 2e-11)
 					double x = 0, y = 0;
 					uint32_t inner = 0;
 					do {                                   // unitDiskSample, src/util.cpp:101-107, bounded
-						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, e.r.key, HXR_DIM_GLOSSY + (uint32_t)k * 64u + ((attempt * 8u + inner) & 63u)), x, y);
+						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, e.r.key, HXR_DIM_GLOSSY + (uint32_t)k * 256u + ((attempt * 16u + inner) & 255u)), x, y);
 						x = x * 2 - 1;
 						y = y * 2 - 1;
 						inner++;
-					} while (x * x + y * y > 1 && inner < 8);
+					} while (x * x + y * y > 1 && inner < 16);
 					x *= scaling;
 					y *= scaling;
 					d3 mn = unit(e.n + (bu * x + bv * y));
 					refl = reflect3(e.r.d, mn);
-					if (!(dot(refl, e.n) < 0) || attempt >= 7) break;
+					if (!(dot(refl, e.n) < 0) || attempt >= 15) break;
 				}
 				cur = e.r;
 				cur.d = refl;

@@ -50,5 +50,5 @@ enum : uint32_t {
 	HXR_DIM_PREPASS = 5,            // sample position inside a 24x24 block of the coarse prepass
 	HXR_DIM_LENS = 16,              // + attempt
 	HXR_DIM_DIRECT_LIGHT = 0x10000, // + light * 4096 + sample
-	HXR_DIM_GLOSSY = 0x2000000      // + sample * 64 + attempt
+	HXR_DIM_GLOSSY = 0x2000000      // + sample * 256 + outer attempt * 16 + disk draw
 };

@@ -868,17 +868,18 @@ static col shade_reflection(ctx_t* cx, int si, const hxr_shader* s, const ray_t*
 			vec refl = n;
 			for (uint32_t attempt = 0;; attempt++) {
 				/* unitDiskSample inside the rejection loop: each outer attempt draws one accepted disk point.  Both loops are
-				   unbounded in the reference; here they stop after 8 turns (p ~ 5e-6 per sample), and the HIP kernel does the same */
+				   unbounded in the reference; here they stop after 16 turns (a disk draw fails 16 times in a row with p = 2e-11; the outer
+				   test fails that often only at grazing incidence), and the HIP kernel does the same */
 				double x = 0, y = 0, u, v;
 				uint32_t inner = 0;
 				int accepted;
 				do {
-					hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, ray->key, 0x2000000u + (uint32_t)i * 64u + ((attempt * 8u + inner) & 63u)), &u, &v);
+					hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, ray->key, 0x2000000u + (uint32_t)i * 256u + ((attempt * 16u + inner) & 255u)), &u, &v);
 					accepted = disk_map(u, v, &x, &y);
 					inner++;
-				} while (!accepted && inner < 8);
+				} while (!accepted && inner < 16);
 				refl = glossy_dir(n, ray->dir, s->glossiness, x, y);
-				if (!(vdot(refl, n) < 0) || attempt >= 7) break;
+				if (!(vdot(refl, n) < 0) || attempt >= 15) break;
 			}
 			nr.dir = refl;
 			nr.key = hxo_child_key(ray->key, si, (uint32_t)i);
