@@ -20,7 +20,7 @@
  *     3                  light choice (word 0) and light sample index (word 2), src/main.cpp:146,152
  *     4                  jitter of that light sample (RectLight::getNthSample, src/lights.cpp:37-41)
  *     0x10000 + L*4096+i jitter of sample i of light L in direct lighting (src/shading.cpp:78,123)
- *     0x2000000 + k*64+a glossy reflection sample k, rejection attempt a (src/shading.cpp:171-179)
+ *     0x2000000 + k*256 + a*16 + i  glossy reflection sample k, rejection attempt a, disk draw i (src/shading.cpp:171-179)
  * Ray keys: the camera ray has key 0; a ray spawned by shader S (table index) as its k-th ray from a
  * ray with key K gets (K ^ (S + 1)) * 2654435761 + k  (mod 2^32).
  */
