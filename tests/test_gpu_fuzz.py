@@ -110,7 +110,7 @@ def make_scene(seed, geom_dir=None, without=()):
     return "".join(t), mode
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("HXR_FUZZ_SEEDS", "60"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HXR_FUZZ_FIRST", "0")), int(os.environ.get("HXR_FUZZ_FIRST", "0")) + int(os.environ.get("HXR_FUZZ_SEEDS", "60"))))
 def test_random_scene_matches_oracle(gpu, tmp_path, seed):
     text, mode = make_scene(seed, os.path.relpath(os.path.join(ROOT, "data", "geom"), tmp_path))
     path = os.path.join(tmp_path, "fuzz_%d.hexray" % seed)
