@@ -103,12 +103,14 @@ def test_hexray_binary_as_a_child_process(gpu, tmp_path):
     assert os.path.exists(exe), "build.sh cli has not been run"
     hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(320, 240, dof=True, num_samples=8))
     want = hx.DeviceScene(hs).render(hx.frame_params())
-    for extra in ([], ["--devices", "0,0"], ["--progress", "--tile", "32"]):
+    for extra in ([], ["--devices", "0,0"], ["--progress", "--tile", "32"], ["--accel", "device-build"]):   # the last: kd-trees built on the GPU
         raw = tmp_path / "frame.raw"
         r = subprocess.run([exe, scene_path("meshes.hexray"), "--width", "320", "--height", "240", "--dof", "on", "--spp", "8", "--out", str(raw)] + extra,
                            capture_output=True, text=True, timeout=120, cwd=ROOT)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "Exited cleanly" in r.stdout and "nodes            : 6007" in r.stdout
+        if "device-build" in extra:
+            assert "built on the GPU" in r.stdout and "leaf entries     : 33644" in r.stdout
         blob = np.fromfile(raw, dtype=np.uint8)
         w, h = np.frombuffer(blob[:8].tobytes(), dtype=np.int32)
         frame = np.frombuffer(blob[8:].tobytes(), dtype=np.float32).reshape(h, w, 3)
@@ -116,6 +118,16 @@ def test_hexray_binary_as_a_child_process(gpu, tmp_path):
         if "--progress" in extra:
             assert "tiles reported: 80" in r.stdout
         raw.unlink()
+    # heightfield.hexray with every table of the heightfield prepared by the module: close to the host-prepared frame (float rounding of the blur)
+    frames = []
+    for extra in ([], ["--gpu-heightfield-blur"]):
+        raw = tmp_path / "hf.raw"
+        r = subprocess.run([exe, scene_path("heightfield.hexray"), "--width", "240", "--height", "180", "--aa", "off", "--out", str(raw)] + extra,
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode == 0 and "Exited cleanly" in r.stdout, r.stdout + r.stderr
+        frames.append(np.frombuffer(np.fromfile(raw, dtype=np.uint8)[8:].tobytes(), dtype=np.float32).reshape(180, 240, 3).astype(np.float64))
+        raw.unlink()
+    assert np.sqrt(np.mean((frames[0] - frames[1]) ** 2, axis=(0, 1))).max() <= 1e-4
 
 
 def test_scene_tables_prepared_on_the_gpu(gpu):
