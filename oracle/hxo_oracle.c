@@ -732,11 +732,11 @@ static int visible(ctx_t* cx, vec A, vec B)
 	ray.dir = vunit(vsub(B, A));
 	for (int64_t i = 0; i < cx->sc->num_nodes; i++) {
 		hit_t h;
-		if (node_hit(cx, (int)i, &ray, &h) && h.dist < D) return 0;
+		if (node_hit(cx, (int)i, &ray, &h) && h.dist < D) { cx->cnt.reserved_[0]++; return 0; }   /* reserved_[0]: shadow queries that found an occluder */
 	}
 	for (int64_t i = 0; i < cx->sc->num_lights; i++) {
 		double d = D;
-		if (light_hit(cx->sc->lights + i, &ray, &d)) return 0;
+		if (light_hit(cx->sc->lights + i, &ray, &d)) { cx->cnt.reserved_[0]++; return 0; }
 	}
 	return 1;
 }
