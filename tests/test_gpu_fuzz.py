@@ -199,3 +199,34 @@ def test_random_scene_other_render_modes(gpu, tmp_path, seed):
         rms = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2, axis=(0, 1)))
         assert rms.max() <= 1e-4, (seed, fp, rms)
         assert gc["camera_samples"] == oc["camera_samples"] and abs(gc["raycasts"] - oc["raycasts"]) <= 8, (seed, fp, gc["raycasts"], oc["raycasts"])
+
+
+@pytest.mark.parametrize("seed", (1, 2, 3, 5))
+def test_random_scene_under_a_moving_camera(gpu, tmp_path, seed):
+    """hxr_scene_update_camera on generated scenes: after every move the frame equals the oracle's for the moved camera -- the cost map
+    the adaptive schedule carries over from the previous camera position may only reorder work -- and sharded adaptive-AA frames (halo
+    pixels, pass-1 schedule) still assemble to the whole frame."""
+    import random as _r
+    text, mode = make_scene(seed, os.path.relpath(os.path.join(ROOT, "data", "geom"), tmp_path))
+    path = os.path.join(tmp_path, "fuzz_%d.hexray" % seed)
+    with open(path, "w") as f:
+        f.write(text)
+    hs = hx.HostScene(path)
+    ds = hx.DeviceScene(hs)
+    r = _r.Random(seed)
+    for step in range(4):
+        hs.move_camera(r.uniform(-3, 3), r.uniform(-2, 4))
+        hs.rotate_camera(r.uniform(-8, 8), r.uniform(-3, 3))
+        ds.update_camera()
+        got = ds.render(hx.frame_params())
+        want, _ = oracle_render(hs, hx.frame_params())
+        rms = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2, axis=(0, 1)))
+        assert rms.max() <= 1e-4, (seed, mode, step, rms)
+    if mode == "aa":
+        whole = ds.render(hx.frame_params(mode=hx.MODE_ADAPTIVE_AA))
+        for count in (2, 3):
+            acc = np.zeros_like(whole)
+            for rank in range(count):
+                part = ds.render(hx.frame_params(mode=hx.MODE_ADAPTIVE_AA, tile_size=16, shard_rank=rank, shard_count=count))
+                acc += part          # LAYOUT_FRAME: a rank's frame holds its own tiles and zeros elsewhere
+            assert np.array_equal(acc, whole), (seed, count)
