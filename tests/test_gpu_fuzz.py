@@ -133,7 +133,7 @@ def test_random_scene_matches_oracle(gpu, tmp_path, seed):
     ds.close()
 
 
-@pytest.mark.parametrize("seed", range(2, 26, 2))
+@pytest.mark.parametrize("seed", range(2, 2 + 2 * int(os.environ.get("HXR_FUZZ_ENTRY_SEEDS", "12")), 2))
 def test_random_scene_through_the_other_entry_points(gpu, tmp_path, seed):
     """The same generated scenes through what else the ABI offers, each against the plain frame: three shards assembled on the GPU, an
     odd tile size, a repeated frame (the adaptive schedule at work), deferred secondary rays, a scene whose kd-trees / heightfield tables
