@@ -2027,8 +2027,9 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 // Waves per SIMD the register allocator must leave room for (template parameter W of the kernel; measured on
 // MI355X): kernels that walk kd-trees are fastest at 3 (168 VGPRs, ~220 spilled: the packet walk
 // needs the latency hiding more than the registers) -- mesh-only Whitted, and the catch-all variants on scenes
-// with meshes (12 % faster than at 2); the heightfield marcher and the sphere path tracer keep more per-lane
-// state alive and are 16 % / 21 % faster at 2 (256 VGPRs, almost nothing spilled).
+// with meshes (12 % faster than at 2); the heightfield marcher keeps more per-lane state alive and is 18 % faster at 2
+// (256 VGPRs, almost nothing spilled).  The sphere path tracer was 21 % faster at 2 in round 1 and, since its turns (trace_rays), is
+// 16 % faster at 3 (re-measured at the end of round 2 for every variant: hxr_variants.h).
 // M: the render mode when known at compile time (1 = Monte-Carlo, the throughput mode), -1 = HxrLaunch::mode at run time
 template <bool COUNT, unsigned F, int W, int M>
 __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(

@@ -38,10 +38,13 @@
 	X(false, (HXR_F_MESH | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)                     \
 	X(false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)     \
 	X(true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)
+#ifndef HXR_MESH_GI_WAVES
+#define HXR_MESH_GI_WAVES 3
+#endif
 // hxr_kernels_mesh2.hip: path tracing over meshes and the catch-alls for scenes with meshes
 #define HXR_VARIANTS_MESH_OTHER(X)                                      \
-	X(false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3)   \
-	X(true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), 3)    \
+	X(false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)   \
+	X(true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)    \
 	X(false, (HXR_F_ALL), 3)                                            \
 	X(true, (HXR_F_ALL), 3)                                             \
 	X(false, (HXR_F_ALL & ~HXR_F_GI), 3)                                \
@@ -53,9 +56,15 @@
 	X(false, ((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST), 2)      \
 	X(true, ((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST), 2)
 // hxr_kernels_heightfield.hip
+#ifndef HXR_HEIGHTFIELD_WAVES
+#define HXR_HEIGHTFIELD_WAVES 2   // waves per SIMD of the heightfield kernels (heightfield16: 9.14 ms at 2, 11.2 at 3) and, below, of the sphere path tracer; re-measured at the end of round 2
+#endif
+#ifndef HXR_SPHERE_GI_WAVES
+#define HXR_SPHERE_GI_WAVES 3   // smallpt 16 paths: 37.2 ms at 2, 31.4 at 3, 32.3 at 4 (round 1, before the turns: 2 was 21 % ahead of 3)
+#endif
 #define HXR_VARIANTS_HEIGHTFIELD(X)                  \
-	X(false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2) \
-	X(true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), 2)
+	X(false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), HXR_HEIGHTFIELD_WAVES) \
+	X(true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), HXR_HEIGHTFIELD_WAVES)
 
 #define HXR_INSTANTIATE(C, F, W)                                                    \
 	template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
