@@ -466,7 +466,7 @@ enum { QCTL_WORDS = (2 * HXR_QUEUE_SHARDS + 1) * HXR_SHARD_STRIDE };
 static_assert(HXR_SHARDS == HXR_QUEUE_SHARDS, "one sub-queue per dispenser range");
 
 // Smallest compiled variant that covers the scene's geometry kinds and integrator (see HXR_F_* in hxr_kernels.hip.h); occupancy
-// target: 3 waves/SIMD when kd-trees are walked, else 2 (see the note above hxr_render_kernel).
+// target per variant: measured (see hxr_variants.h and the note above hxr_render_kernel).
 enum Variant { V_MESH, V_MESH_REFRACT, V_HEIGHTFIELD, V_SPHERE_GI, V_MESH_GI, V_ALL_GI_3, V_ALL_GI_2, V_ALL_3, V_ALL_2, V_NESTED_GI, V_NESTED };
 Variant pick_variant(const hxr_scene* s)
 {
@@ -481,8 +481,14 @@ Variant pick_variant(const hxr_scene* s)
 	if (!gi && !rect && geom == HXR_F_HEIGHTFIELD) return V_HEIGHTFIELD;
 	if (gi && (geom | HXR_F_SPHERE) == HXR_F_SPHERE) return V_SPHERE_GI;
 	if (gi && (geom | HXR_F_MESH) == HXR_F_MESH) return V_MESH_GI;
-	if (gi) return meshes ? V_ALL_GI_3 : V_ALL_GI_2;
-	return meshes ? V_ALL_3 : V_ALL_2;
+	// the catch-alls: three waves per SIMD for Whitted, two for path tracing, whatever the geometry (tools/all_waves.py, end of round 2:
+	// boxed.hexray 27 -> 18 ms and hw10/bokeh 15.7 -> 12.9 ms at 3; smallpt + a cube 46 ms at 2 against 77 at 3, cornell box + a cube
+	// 38.2 against 39.1; round 1 chose by "has meshes")
+	bool three = !gi;
+	(void)meshes;
+	if (const char* e = getenv("HXR_ALL_WAVES")) three = atoi(e) == 3;   // developer aid: force the 2- or 3-wave catch-all
+	if (gi) return three ? V_ALL_GI_3 : V_ALL_GI_2;
+	return three ? V_ALL_3 : V_ALL_2;
 }
 
 // Deferred secondary rays: does this launch use them, and with what queue?  Only the Whitted mesh variants have a deferring
