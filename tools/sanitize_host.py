@@ -38,3 +38,29 @@ print("fuzz ok")
 a = np.random.rand(17, 23, 3).astype(np.float32)
 hx.save_bmp(os.path.join(d, "x.bmp"), a); hx.save_exr(os.path.join(d, "x.exr"), a); hx.load_image(os.path.join(d, "x.bmp")); hx.load_image(os.path.join(d, "x.exr"))
 print("io ok")
+# the scene parser on damaged input: 400 random mutations of shipped scene files either load or are refused with a message
+import random
+r = random.Random(7)
+work = tempfile.mkdtemp()
+for sub in ("geom", "texture", "env"):
+    os.symlink(os.path.join(ROOT, "data", sub), os.path.join(work, sub))
+srcs = [open(os.path.join(ROOT, "data", n)).read() for n in ("meshes.hexray", "kdtree_test.hexray", "smallpt.hexray", "heightfield.hexray")]
+loaded = refused = 0
+for i in range(400):
+    b = list(r.choice(srcs))
+    for k in range(r.randint(1, 6)):
+        op, pos = r.random(), r.randrange(len(b))
+        if op < 0.4:
+            del b[pos:pos + r.randint(1, 12)]
+        elif op < 0.7:
+            b[pos:pos] = list(r.choice(["{", "}", "(", ")", "\n", " 1e999 ", " -5 ", "\"", "file \"nope.obj\"", "//", "/*", "Mesh x {", "999999999999"]))
+        else:
+            b[pos] = chr(r.randint(32, 126))
+    p = os.path.join(work, "mutated.hexray")
+    open(p, "w").write("".join(b))
+    try:
+        hx.HostScene(p).close()
+        loaded += 1
+    except ValueError:
+        refused += 1
+print("mutated scene files: %d loaded, %d refused, no crash" % (loaded, refused))
