@@ -49,7 +49,7 @@ WORKLOADS = {
     # no nodes at all: the fixed per-packet cost (sample generation, camera, reduction, store)
     "empty16": ("../tests/golden/tiny.hexray", dict(width=1920, height=1080, dof=True, num_samples=16), "empty scene 1920x1080 x 16 spp (overhead probe)"),
 }
-TILE = 32          # single GPU: only the order of the packets depends on it
+TILE = 64          # single GPU: only the order of the packets depends on it (the reference's bucket size; tools/tile_sweep.py: 8.80-8.85 ms at 64 / 128 / 8, 8.92 at 32)
 SHARD_TILE = 8     # N > 1: tiles are dealt round-robin to the ranks; 8x8 spreads the expensive image regions best (rank time max/mean 1.13 vs 1.35 at 32)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
