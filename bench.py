@@ -60,7 +60,7 @@ def algorithmic_bytes(c, width, height):
             + 48 * c["env_bilinear"] + 4 * (c["hf_highest"] + c["hf_height"]) + 96 * c["hf_normals"] + 12 * width * height)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -69,9 +69,49 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sah-side", action="store_true", help="skip the SAH-tree side measurement (profiling runs: one kernel configuration only)")
     ap.add_argument("--no-other-timings", action="store_true", help="skip the first-frame / no-schedule / host-buffer / deferred-ray side measurements (profiling runs)")
+    ap.add_argument("--no-config5", action="store_true", help="N > 1: skip the smallpt x 256 paths sub-record (BASELINE.json's 8-GPU configuration)")
     ap.add_argument("--accel", default="reference", choices=["reference", "sah"],
                     help="kd-trees walked by the timed frames: the reference's own (default) or the module's SAH rebuild")
-    args = ap.parse_args()
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="launch / join the ranks, agree on the world size over gloo, print it and stop before any GPU work (CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+def launch_command(args, argv, port):
+    """The command that starts one rank per GPU, or None when this process IS a rank (WORLD_SIZE set: the driver's
+    `python -m torch.distributed.run ... bench.py --gpus N` form) or a single GPU is asked for.  The reference's analogue is the
+    thread fan-out of render() (src/main.cpp:273-275,364-367)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as children of THIS process, which has not imported torch,
+    loaded the HIP module or touched a GPU (a process that has must never be replaced by another program), and leave with their
+    exit code: non-zero as soon as one rank fails."""
+    import subprocess
+    cmd = launch_command(args, argv, free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: --gpus %d without WORLD_SIZE: starting the ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if launch_command(args, argv, 0) is not None:      # FIRST thing: no torch, no HIP call before the ranks exist
+        raise SystemExit(self_launch(args, argv))
 
     import numpy as np
     import torch
@@ -89,14 +129,35 @@ def main():
     rehearsal = os.environ.get("HXR_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if args.rendezvous_check:
+        # CPU test of the launch path (tests/test_abi_and_sharding.py): the ranks meet over gloo and count themselves
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            joined = dist.get_world_size()
+            assert int(t.item()) == joined
+            dist.destroy_process_group()
+        else:
+            joined = 1
+        if rank == 0:
+            print(json.dumps({"rendezvous_check": True, "n_gpus": joined, "asked": args.gpus}))
+        if joined != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d ranks joined" % (args.gpus, joined))
+        return
     if world > 1:
+        if not rehearsal and torch.cuda.device_count() < world:   # counting devices does not initialise the GPU
+            raise SystemExit("bench.py: %d ranks but %d GPUs visible (HXR_BENCH_REHEARSAL=1 runs every rank on GPU 0 over gloo)"
+                             % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        world = dist.get_world_size()          # the ranks that actually joined: this is what `n_gpus` reports
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE=%s): refusing to print a line whose n_gpus is not what was asked"
+                         % (args.gpus, world, os.environ.get("WORLD_SIZE")))
 
     scene_name, ov, description = WORKLOADS[args.workload]
     t_prep = time.perf_counter()
@@ -199,6 +260,12 @@ def main():
         if not same:
             raise SystemExit("sharded frame differs from the single-GPU frame")
 
+    config5 = None
+    if world > 1 and not args.no_config5 and args.workload == "meshes16":
+        # BASELINE.json's 8-GPU configuration next to the headline line: data/smallpt.hexray, 1920x1080, 256 paths per pixel, the same
+        # tile shards and the same single gather; 3 timed frames after one set-up frame (max over ranks, like the main line)
+        config5 = sharded_frames(hx, torch, dist, "smallpt256", world, rank, rehearsal, stream, frames=3, setup=1)
+
     other = None
     if world == 1 and rank == 0 and not args.no_other_timings:
         other = other_timings(hx, hs, accel, W, H, stream, torch, np, min(args.steps, 10))
@@ -219,7 +286,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "scene asset data/%s shipped with the reference (no external dataset); Monte-Carlo modes: frames agree with the CPU oracle run on the same "
-                    "counter-based generator, agreement with the reference's own mt19937 statistics is not verifiable here (DESIGN.md section 4)" % scene_name,
+                    "counter-based generator, agreement with the reference's own mt19937 statistics is not verifiable here (DESIGN.md section 4)%s"
+                    % (scene_name, "; this scene's EXR cubemap is decoded by the module's own PIZ reader, whose texels are UNPINNED (no OpenEXR decoder in the image "
+                                   "to compare with: DESIGN.md section 4)" if scene_name in ("simple.hexray", "heightfield.hexray") else ""),
             "config": {"workload": description, "width": W, "height": H, "spp": spp if spp > 0 else 1, "tile_size": TILE if world == 1 else SHARD_TILE,
                        "accel": "reference kd-tree (as handed over by the host)" if accel == hx.ACCEL_REFERENCE else "SAH kd-tree rebuilt by the module",
                        "parallelism": "tile-shard x%d, one RCCL gather" % world if world > 1 else "single GPU", "rng_seed": int(probe.rng_seed)},
@@ -250,6 +319,8 @@ def main():
         else:
             result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                   "kernel_ms": round(kernel_ms_mean, 4), "note": "per-rank kernel time of rank 0; counters are collected at N=1 only"}
+        if config5 is not None:
+            result["config5_smallpt256"] = config5
         if other is not None:
             result["other_timings"] = other
             result["value_is"] = ("steady-state frames (schedule seeded by the previous identical frame; %d untimed set-up frames before the warm-up), "
@@ -293,6 +364,57 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def sharded_frames(hx, torch, dist, workload, world, rank, rehearsal, stream, frames, setup):
+    """`frames` frames of another workload through the N-rank pipeline of the main line (round-robin tile shards, one gather, assembly on
+    rank 0), timed the same way: barrier + synchronize on both sides, max over ranks.  Returns the sub-record on every rank."""
+    from hexray_amd.distributed import gather_tiles, padded_tiles_per_rank
+    scene_name, ov, description = WORKLOADS[workload]
+    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+    ds = hx.DeviceScene(hs, accel=hx.ACCEL_REFERENCE)
+    W, H = hs.settings.frame_width, hs.settings.frame_height
+    spp = max(hs.camera.num_samples if hs.camera.dof else 0, hs.settings.num_paths if hs.settings.gi else 0) or 1
+    T = SHARD_TILE
+    slots = padded_tiles_per_rank(W, H, T, world)
+    local = torch.zeros(slots * T * T * 3, dtype=torch.float32, device="cuda")
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+    landing = torch.empty(world * local.numel(), dtype=torch.float32, device="cuda") if rank == 0 and not rehearsal else None
+    params = hx.frame_params(tile_size=T, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
+
+    def step():
+        ds.render_device(params, local.data_ptr(), 0, stream)
+        if rehearsal:
+            torch.cuda.synchronize()
+            got = gather_tiles(local.cpu(), world, rank)
+            gathered = got.cuda() if rank == 0 else None
+        else:
+            gathered = gather_tiles(local, world, rank, out=landing)
+        if rank == 0:
+            ds.assemble_frame(params, gathered.data_ptr(), slots * T * T * 12, frame.data_ptr(), W * 12, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(setup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = ds.last_kernel_ms()
+    ds.close()
+    hs.close()
+    return {"workload": description, "frames": frames, "ms_per_frame": round(elapsed / frames * 1e3, 3),
+            "Msamples_per_s": round(W * H * spp * frames / elapsed / 1e6, 2), "rank0_kernel_ms_last_frame": round(float(kernel_ms), 3),
+            "tile_size": T, "parallelism": "tile-shard x%d, one gather" % world}
 
 
 def other_timings(hx, hs, accel, W, H, stream, torch, np, frames):

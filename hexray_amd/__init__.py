@@ -484,8 +484,7 @@ class DeviceGroup:
         if not self._g:
             raise HipError("hxr_group_create failed: " + hip_lib().hxr_last_error().decode(errors="replace"))
         self.host = host_scene
-        global _initialised_device
-        _initialised_device = devices[0]
+        # hxr_group_create leaves the process-wide device selection as it found it: a DeviceScene created later still calls init()
 
     def render(self, params: FrameParams | None = None, cancel=None, on_tile=None) -> np.ndarray:
         params = params or frame_params()

@@ -87,6 +87,7 @@ struct hxr_scene {
 	hxr_settings settings;
 	hxr_camera camera;
 	unsigned features = 0;          // HXR_F_* geometry kinds present among the nodes
+	int num_cu = 256;               // compute units of THIS scene's device (grids are sized per scene: a group may mix devices)
 	struct TreeStats { int64_t nodes, leaf_entries; int depth; };
 	std::vector<TreeStats> tree_stats;   // per mesh: the tree actually walked
 	double kd_build_ms = 0;              // HXR_ACCEL_REFERENCE_DEVICE_BUILD: time of the kd builds on the GPU, all meshes
@@ -339,6 +340,7 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, const hxr_kd_
 	const size_t kd0 = kd.size();
 	kd.resize(kd0 + (size_t)num_nodes);
 	boxes.resize(kd0 + (size_t)num_nodes);
+	o.boxes_nested = 1;
 	struct Item { int node; int depth; double lo[3], hi[3]; };
 	std::vector<Item> todo;
 	Item root;
@@ -362,6 +364,9 @@ int append_mesh_tables(const hxr_scene_desc* d, const hxr_mesh& m, const hxr_kd_
 		}
 		r.first = n.first;
 		r.axis_count = n.axis;
+		// every split position inside its node's box <=> every node's box inside its parent's: mesh_query's shortcut for the
+		// inflated inside() test relies on it (true for the reference's midpoints and for the SAH builder's planes)
+		if (!(n.split >= it.lo[n.axis] && n.split <= it.hi[n.axis])) o.boxes_nested = 0;
 		Item L = it, R = it;   // BBox::split: the children copy the box and replace one bound by the split position
 		L.node = n.first;
 		R.node = n.first + 1;
@@ -451,10 +456,10 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 	L.fov_radius = p.fovea; L.vip_x = p.vip_x; L.vip_y = p.vip_y;
 }
 
-int grid_for(uint32_t chunks)
+int grid_for(const hxr_scene* s, uint32_t chunks)
 {
 	// persistent waves: enough blocks to fill every CU several times over, never more than the work
-	uint32_t blocks = (uint32_t)g_num_cu * 8u;
+	uint32_t blocks = (uint32_t)s->num_cu * 8u;
 	uint32_t need = (chunks + (HXR_BLOCK / 64) - 1) / (HXR_BLOCK / 64);
 	return (int)std::max(1u, std::min(blocks, need));
 }
@@ -547,7 +552,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 	const HxrSceneDev& V = s->host_view;
 #define HXR_KERNEL_ARGS s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L
 	if (L.num_chunks > 0) {
-		int grid = grid_for(L.num_chunks);
+		int grid = grid_for(s, L.num_chunks);
 #define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                      \
 	do {                                                                                                                                                      \
 		if (L.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);     \
@@ -606,12 +611,12 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		// per-lane walk unless its stacks would not fit the 64 KB a block may take (trees deeper than 126 levels), or HXR_CONTINUE_PACKET=1 (A/B aid)
 		const bool lanewalk = lane_lds <= 64 * 1024 - 4096 && !getenv("HXR_CONTINUE_PACKET");
 		if (lanewalk) {
-			const int cgrid = std::max(1, g_num_cu * 16);
+			const int cgrid = std::max(1, s->num_cu * 16);
 			if (counters) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES>), dim3(cgrid), dim3(HXR_LANE_BLOCK), lane_lds, st, HXR_KERNEL_ARGS);
 			else if (refract) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES>), dim3(cgrid), dim3(HXR_LANE_BLOCK), lane_lds, st, HXR_KERNEL_ARGS);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH | HXR_F_LANEWALK), HXR_LANEWALK_WAVES>), dim3(cgrid), dim3(HXR_LANE_BLOCK), lane_lds, st, HXR_KERNEL_ARGS);
 		} else {
-			const int cgrid = std::max(1, g_num_cu * 4);
+			const int cgrid = std::max(1, s->num_cu * 4);
 			if (counters) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<true, (HXR_F_MESH | HXR_F_REFRACT), 3>), dim3(cgrid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);
 			else if (refract) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH | HXR_F_REFRACT), 3>), dim3(cgrid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_continue_kernel<false, (HXR_F_MESH), 3>), dim3(cgrid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);
@@ -619,7 +624,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(s->ev_pass[pass][2], st));
 		const uint32_t pixels = (uint32_t)p.ntiles * (uint32_t)(p.tile * p.tile) + (uint32_t)L.num_extra_pixels;
-		const int rgrid = (int)std::max(1u, std::min<uint32_t>((pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)g_num_cu * 8u));
+		const int rgrid = (int)std::max(1u, std::min<uint32_t>((pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * 8u));
 		hipLaunchKernelGGL(hxr_resolve_kernel, dim3(rgrid), dim3(HXR_BLOCK), 0, st, L, scale);
 		HIP_TRY(hipGetLastError());
 		s->accum_dirty = false;   // enqueued: the accumulator is zero again when this stream gets there
@@ -687,7 +692,7 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		if (const char* e = getenv("HXR_SCHED_FRAME_DIV")) frame_div = (uint32_t)atoi(e);
 		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
-		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)g_num_cu * 12u, frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
+		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * 12u, frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
 		HIP_TRY(hipGetLastError());
 	} else {
@@ -774,7 +779,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (p.layout == HXR_LAYOUT_FRAME && stride < (size_t)p.W * 12) { set_err("row stride smaller than a row"); return HXR_E_INVALID; }
 	const bool counters = fp->collect_counters != 0;
-#if defined(HXR_PHASE_TIMERS) || defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS)
+#if defined(HXR_PHASE_TIMERS) || defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS) || defined(HXR_LEAF_HIST) || defined(HXR_WALK_STATS)
 	const bool want_counter_buffer = true;    // profiling build: the phase clocks land in hxr_counters.reserved_
 #else
 	const bool want_counter_buffer = counters;
@@ -898,7 +903,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		}
 		uint32_t heavy_x = 16;   // frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list)
 		if (const char* e = getenv("HXR_AA_HEAVY_X")) heavy_x = (uint32_t)atoi(e);   // developer aid
-		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)g_num_cu * 8u);
+		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * 8u);
 		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512),
 		                   cost_aware ? (const uint32_t*)s->d_sched_cost : (const uint32_t*)nullptr, (const unsigned long long*)s->d_sched_ctl, L.num_chunks,
 		                   cost_aware ? (uint32_t*)s->d_sched_ctl + 3 : (uint32_t*)nullptr, list_capacity, heavy_x);
@@ -981,9 +986,13 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		if (accel != HXR_ACCEL_REFERENCE && accel != HXR_ACCEL_SAH && accel != HXR_ACCEL_REFERENCE_DEVICE_BUILD) { set_err("unknown acceleration structure %d", accel); return nullptr; }
 	}
 	const bool adaptive = !(opt && opt->no_adaptive_schedule) && !getenv("HXR_NO_ADAPTIVE_SCHEDULE");
+	// allocations and launches below go to the CURRENT device of the calling thread: make that the device hxr_init chose, whatever
+	// the thread has been bound to since (hxr_group_create walks over several devices)
+	if (hipSetDevice(g_device) != hipSuccess) { set_err("hipSetDevice(%d) failed", g_device); return nullptr; }
 	hxr_scene* s = new hxr_scene;
 	s->adaptive = adaptive;
 	s->device = g_device;
+	s->num_cu = g_num_cu;
 	s->defer_allowed = ((opt && opt->deferred_rays) || getenv("HXR_DEFER")) && !getenv("HXR_NO_DEFER");
 	for (int64_t i = 0; i < d->num_nodes; i++) {   // validate() has bounded this walk
 		int rays = 0, pending = 1;
@@ -1287,7 +1296,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	s->d_work = (uint32_t*)p;
 	if (s->arena.alloc(sizeof(hxr_counters), &p)) return fail();
 	s->d_counters = (unsigned long long*)p;
-#if defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS)
+#if defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS) || defined(HXR_LEAF_HIST) || defined(HXR_WALK_STATS)
 	V.dev_stats = s->d_counters + HC_NUM;
 #endif
 	const HxrSceneDev* dv = nullptr;
@@ -1413,6 +1422,10 @@ int hxr_render(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_
 		s->watch_words = words;
 	}
 	HIP_TRY(hipMemsetAsync(s->d_watch, 0, words * sizeof(uint32_t), s->main_stream));
+	// The poll below reads these words on aux_stream, which nothing else orders against main_stream: without this the first look could
+	// run before the clear and see hipMalloc's garbage or the previous frame's "every tile complete" counts.
+	HIP_TRY(hipEventRecord(s->ev_done, s->main_stream));
+	HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_done, 0));
 	rc = ensure_cancel_word(s);
 	if (rc) return rc;
 	if (p.count > 1) HIP_TRY(hipMemsetAsync(s->d_frame, 0, dstride * p.H, s->main_stream));
@@ -1885,6 +1898,12 @@ hxr_group* hxr_group_create(const hxr_scene_desc* desc, const hxr_scene_options*
 {
 	if (!device_ids || num_devices <= 0 || num_devices > 64) { set_err("bad device list"); return nullptr; }
 	hxr_group* g = new hxr_group;
+	// hxr_init() moves the process-wide selection (g_device, g_num_cu) from replica to replica; what the caller had chosen before the group
+	// is put back on every way out, so that a plain hxr_scene_create() afterwards lands on the caller's device, not on the group's last one
+	struct Restore {
+		int device, num_cu;
+		~Restore() { g_device = device; g_num_cu = num_cu; if (device >= 0) (void)hipSetDevice(device); }
+	} restore{g_device, g_num_cu};
 	for (int d = 0; d < num_devices; d++) {
 		if (hxr_init(device_ids[d])) { hxr_group_destroy(g); return nullptr; }   // binds the calling thread to the device and records its size
 		hxr_scene* s = hxr_scene_create_ex(desc, options);
@@ -1903,9 +1922,25 @@ hxr_group* hxr_group_create(const hxr_scene_desc* desc, const hxr_scene_options*
 		g->arrived.push_back(ev);
 		g->d_tiles.push_back(nullptr);
 		g->tiles_bytes.push_back(0);
-		if (d > 0 && device_ids[d] != device_ids[0]) {   // direct xGMI copies where the platform allows them (the copy works either way)
+		if (d > 0 && device_ids[d] != device_ids[0]) {
+			// Device d pushes its tile buffer into device 0's landing buffer (hipMemcpyPeerAsync on d's stream).  The current device here is
+			// device_ids[d] (hxr_init above), so this enables d -> 0 access, the direction of that copy.  Without peer access the runtime
+			// would stage the copy through the host -- a path this module has never run (one-GPU test boxes list device 0 several times) --
+			// so a platform that refuses it is reported, not silently used.
 			int can = 0;
-			if (hipDeviceCanAccessPeer(&can, device_ids[d], device_ids[0]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+			if (hipDeviceCanAccessPeer(&can, device_ids[d], device_ids[0]) != hipSuccess || !can) {
+				(void)hipGetLastError();
+				set_err("device %d cannot access device %d peer-to-peer: hxr_group needs direct (xGMI / PCIe P2P) copies into the first device", device_ids[d], device_ids[0]);
+				hxr_group_destroy(g);
+				return nullptr;
+			}
+			hipError_t pe = hipDeviceEnablePeerAccess(device_ids[0], 0);
+			if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+				set_err("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", device_ids[d], device_ids[0], hipGetErrorString(pe));
+				(void)hipGetLastError();
+				hxr_group_destroy(g);
+				return nullptr;
+			}
 			(void)hipGetLastError();
 		}
 	}

@@ -46,7 +46,9 @@ struct HxrMeshDev {
 	int32_t kd_first;              // this mesh's nodes in the concatenated kd arrays (node 0 of the range = root); odd, so that
 	                               // child pairs (local indices 1-2, 3-4, ...) start at even global indices
 	int32_t hot_first;             // this mesh's leaf-ordered (has_kd) or triangle-ordered (no kd) hot records / triangle ids
-	int32_t pad_[2];
+	int32_t boxes_nested;          // every kd node's box lies inside its parent's (split positions inside their node's box): an origin
+	                               // outside the inflated root box is then outside every node's inflated box (mesh_query)
+	int32_t pad_;
 	const hxr_triangle* tris;      // cold records of this mesh
 	const double* vertices;        // 3 doubles each (element 0 = sentinel)
 	const double* normals;

@@ -296,8 +296,9 @@ HXR_DEV double box_nearest(const Box& b, d3 o, d3 d)   // BBox::closestIntersect
 // ------------------------------------------------------------------------------------------------
 struct GeomHit {
 	double t;        // object-space distance (info.dist inside geometry code)
-	double l2, l3;   // mesh barycentrics
-	int tri;         // mesh triangle number / cube face (axis*2 + side)
+	int tri;         // mesh: index of the accepted triangle's hot record (scene-wide: HxrSceneDev::hot / hot_ids) / cube face (axis*2 + side)
+	// The barycentrics of a mesh hit are not carried: surface_of() forms them again for the ONE hit a ray keeps, with the expressions
+	// of the test (tri_products), instead of every candidate dragging two doubles through the node scan in two copies (8 VGPRs).
 };
 
 HXR_DEV bool plane_query(const double* p, d3 o, d3 d, GeomHit& g)   // Plane::intersect, src/geometry.cpp:31-50
@@ -522,7 +523,8 @@ HXR_DEV void csg_rehit_any(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3
 #define HXR_KD_STACK 200     // at most three entries per level of a depth-66 tree
 struct WaveStack {
 	int32_t node[HXR_KD_STACK];
-	uint32_t mask_lo[HXR_KD_STACK], mask_hi[HXR_KD_STACK];
+	uint32_t mask_lo[HXR_KD_STACK], mask_hi[HXR_KD_STACK];   // lanes that enter the node when its turn comes (if still searching)
+	uint32_t due_lo[HXR_KD_STACK], due_hi[HXR_KD_STACK];     // instrumented builds: lanes whose BBox::testIntersect of this node is counted then
 };
 // Per-lane traversal stack of the per-lane walk (mesh_query_lane): a column of 32-bit node numbers per lane in LDS
 struct LaneStack {
@@ -538,25 +540,41 @@ struct Stacks {
 };
 #define HXR_PEND_DWORDS 18   // RayItem: o, d (6 dwords each), weight (3), depth, flags, key
 
+// The four products of Mesh::intersectTriangle (src/mesh.cpp:178-195): Dcr = (ABxAC).(-d), and the numerators of gamma, lambda2, lambda3.
+// One definition for the test (record wave-uniform, in scalar registers) and for surface_of(), which forms the barycentrics of the
+// accepted hit again from the same expressions.
+HXR_DEV void tri_products(d3 N, d3 A, d3 AB, d3 AC, d3 o, d3 nd, double& Dcr, double& ga, double& gb, double& gc)
+{
+	Dcr = dot(N, nd);
+	d3 H = o - A;
+	ga = dot(N, H);
+	gb = dot(cross(H, AC), nd);
+	gc = dot(cross(AB, H), nd);
+}
+
+// BBox::inside (src/bbox.h:78-85) with the slack handed in: the leaf loop passes an OPAQUE 1e-6 so that the six inflated bounds are
+// formed where a triangle is accepted (rare) instead of being hoisted out of the loop into twelve vector registers
+HXR_DEV bool box_holds_eps(const Box& b, d3 p, double eps)
+{
+	return b.lo.x - eps <= p.x && p.x <= b.hi.x + eps && b.lo.y - eps <= p.y && p.y <= b.hi.y + eps && b.lo.z - eps <= p.z && p.z <= b.hi.z + eps;
+}
+
 // Mesh::intersectTriangle (src/mesh.cpp:178-195) against the running best hit `g`, and the leaf rule of Mesh::intersectKD
 // (src/mesh.cpp:228): returns true when the triangle is accepted AND its hit point lies in the leaf's box.  One definition for the
-// packet walk (record and index wave-uniform: scalar loads) and the per-lane walk (vector loads).
-HXR_DEV bool triangle_test(const HxrMeshDev& M, const HxrTriHot& T, int id, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g)
+// packet walk (record and index wave-uniform: scalar loads) and the per-lane walk (vector loads).  `hot` = the record's scene-wide index.
+template <bool BACKFACE>
+HXR_DEV bool triangle_test(const HxrSceneDev& S, const HxrMeshDev& M, const HxrTriHot& T, int hot, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g)
 {
 	bool ok = true;
-	if (M.backface_culling) {
-		const HXR_GLOBAL hxr_triangle& ct = in_hbm(M.tris)[id];
+	if constexpr (BACKFACE) {
+		const HXR_GLOBAL hxr_triangle& ct = in_hbm(M.tris)[S.hot_ids[hot]];
 		ok = !(dot(d, ld3(ct.gnormal)) > 0);
 	}
 	// The four sign / magnitude rejections are evaluated without branching between them: the lanes of a
 	// packet fail at different ones, so nested early-outs only add mask bookkeeping (8 levels of it).
-	d3 N = ld3(T.N);
-	double Dcr = dot(N, nd);
-	d3 H = o - ld3(T.A);
-	bool neg = Dcr < 0;
-	double ga = dot(N, H);
-	double gb = dot(cross(H, ld3(T.AC)), nd);
-	double gc = dot(cross(ld3(T.AB), H), nd);
+	double Dcr, ga, gb, gc;
+	tri_products(ld3(T.N), ld3(T.A), ld3(T.AB), ld3(T.AC), o, nd, Dcr, ga, gb, gc);
+	const bool neg = Dcr < 0;
 	ok = ok & !(fabs(Dcr) < 1e-12)
 	        & !(((ga < 0) != neg) & (ga != 0))    // gamma < 0
 	        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
@@ -569,10 +587,10 @@ HXR_DEV bool triangle_test(const HxrMeshDev& M, const HxrTriHot& T, int id, cons
 		bool take = !(gamma < 0 || gamma > g.t) & !(l2 < 0 || l2 > 1) & !(l3 < 0 || l3 > 1) & !(l1 < 0 || l1 > 1);
 		if (take) {
 			g.t = gamma;
-			g.l2 = l2;
-			g.l3 = l3;
-			g.tri = id;
-			inside = box_holds(box, o + d * gamma);
+			g.tri = hot;
+			double eps = 1e-6;
+			asm volatile("" : "+v"(eps));
+			inside = box_holds_eps(box, o + d * gamma, eps);
 		}
 	}
 	return inside;
@@ -585,38 +603,91 @@ HXR_DEV bool triangle_test(const HxrMeshDev& M, const HxrTriHot& T, int id, cons
 // the order of its terms, and  x*rD < 0  <=>  x and Dcr have opposite signs (x != 0), so the three
 // "negative" rejections are decided from signs alone BEFORE the FP64 division is paid for.
 // `first` / `count` are wave-uniform: the hot records (contiguous, leaf order) arrive through scalar loads
-// and stay in SGPRs, so a triangle costs the lanes no vector registers.
+// and stay in SGPRs, so a triangle costs the lanes no vector registers.  The triangle NUMBER of a record (hot_ids) is not read
+// here: a hit remembers its record, surface_of() looks the number up for the one hit a ray keeps.
+// `mask`: the lanes taking part (wave-uniform); returns the lanes that found a hit inside the leaf's box.
 template <bool COUNT>
-HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, bool mine, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g,
-                        const Stacks& st, Tally<COUNT>& tl)
+HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, unsigned long long mask, const Box& box, d3 o, d3 d, d3 nd,
+                                      GeomHit& g, Tally<COUNT>& tl)
 {
-	bool found = false;
 	tl.template lap<PH_MESH>();
-#ifdef HXR_LEAF_STATS   // developer aid: how many lanes take part in a leaf visit (would testing ray x triangle pairs in parallel pay?)
+#if defined(HXR_LEAF_STATS) || defined(HXR_LEAF_HIST)   // developer aids: how many lanes take part in a leaf visit (would testing ray x triangle pairs in parallel pay?)
 	{
-		const unsigned long long part = hxr_ballot(mine);
-		const int k = __popcll(part), me_ = threadIdx.x & 63;
-		if (part && __builtin_amdgcn_readfirstlane(me_) == me_ && S.dev_stats) {
+		const int k = __popcll(mask), me_ = threadIdx.x & 63;
+		if (mask && __builtin_amdgcn_readfirstlane(me_) == me_ && S.dev_stats) {
+#ifdef HXR_LEAF_STATS
 			atomicAdd(S.dev_stats + 0, (unsigned long long)count);
 			const int coop = 2 + (3 * k) / 2;
 			atomicAdd(S.dev_stats + 1, (unsigned long long)(count < coop ? count : coop));
 			atomicAdd(S.dev_stats + 2, 1ull);
 			atomicAdd(S.dev_stats + 3, (unsigned long long)k);
 			if (count == 0) atomicAdd(S.dev_stats + 4, 1ull);   // visits of EMPTY leaves
+#else                   // leaf visits and their triangle iterations by the number of lanes taking part (<= 2, 3..8, >= 33)
+			const int b = k <= 2 ? 0 : (k <= 8 ? 2 : (k >= 33 ? 4 : -1));
+			if (b >= 0) { atomicAdd(S.dev_stats + b, 1ull); atomicAdd(S.dev_stats + b + 1, (unsigned long long)count); }
+#endif
 		}
 	}
 #endif
-	const HxrTriHot* T = S.hot + (M.hot_first + first);
-	const int32_t* ids = S.hot_ids + (M.hot_first + first);
-	if (mine) {
-		for (int i = 0; i < count; i++) {
-			tl.add(HC_TRI);
-			tl.add(HC_LEAFIDX);
-			if (triangle_test(M, T[i], ids[i], box, o, d, nd, g)) found = true;
+	const int base = M.hot_first + first;
+	const HxrTriHot* T = S.hot + base;
+	int hits = 0;   // per lane, touched only where a triangle is accepted: no mask bookkeeping per iteration
+	if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+		if (M.backface_culling) {
+			for (int i = 0; i < count; i++) {
+				tl.add(HC_TRI);
+				tl.add(HC_LEAFIDX);
+				hits |= (int)triangle_test<true>(S, M, T[i], base + i, box, o, d, nd, g);
+			}
+		} else {
+			for (int i = 0; i < count; i++) {
+				tl.add(HC_TRI);
+				tl.add(HC_LEAFIDX);
+				hits |= (int)triangle_test<false>(S, M, T[i], base + i, box, o, d, nd, g);
+			}
 		}
 	}
+	// formed OUTSIDE the divergent region: a wave-uniform value assigned under a lane mask is only defined for the lanes of that mask
+	const unsigned long long found = hxr_ballot(hits != 0);
 	tl.template lap<PH_LEAF>();
 	return found;
+}
+
+// BBox::testIntersect (slab form: box_hit) of BOTH children of a kd node for one ray.  The children's boxes are the node's with one
+// bound of axis A replaced by the split position (BBox::split, src/bbox.h:210-216), so five of the six wall distances are the
+// node's own and are formed once; every value is the very product box_hit() would form for the child's box, and the maxima / minima
+// are exact operations whose grouping does not matter: `left` / `right` are box_hit()'s answers bit for bit.
+// `origin_in_root`: this lane's origin lies in the mesh's inflated root box.  Node boxes nest (HxrMeshDev::boxes_nested), so a lane
+// outside the root's is outside every node's: the inflated inside() shortcut (src/bbox.h:95) is only evaluated for lanes inside.
+template <int A>
+HXR_DEV void kd_children_hit_axis(const Box& b, double split, d3 o, d3 inv, bool origin_in_root, unsigned long long mask, bool& left, bool& right)
+{
+	constexpr int U = (A + 1) % 3, V = (A + 2) % 3;
+	const double lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z};
+	const double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+	const double tu0 = (lo[U] - oo[U]) * ii[U], tu1 = (hi[U] - oo[U]) * ii[U];
+	const double tv0 = (lo[V] - oo[V]) * ii[V], tv1 = (hi[V] - oo[V]) * ii[V];
+	const double ta0 = (lo[A] - oo[A]) * ii[A], ta1 = (hi[A] - oo[A]) * ii[A], ts = (split - oo[A]) * ii[A];
+	const double near_uv = fmax(fmin(tu0, tu1), fmin(tv0, tv1)), far_uv = fmin(fmax(tu0, tu1), fmax(tv0, tv1));
+	const double tnl = fmax(near_uv, fmin(ta0, ts)), tfl = fmin(far_uv, fmax(ta0, ts));   // left child: [lo, split] on axis A
+	const double tnr = fmax(near_uv, fmin(ts, ta1)), tfr = fmin(far_uv, fmax(ts, ta1));   // right child: [split, hi]
+	left = tnl <= tfl && tfl >= 0;
+	right = tnr <= tfr && tfr >= 0;
+	if (hxr_ballot(origin_in_root && !(left && right)) & mask) {   // BBox::inside of the child boxes, when it can matter to a lane of the visit
+		const bool in_uv = lo[U] - 1e-6 <= oo[U] && oo[U] <= hi[U] + 1e-6 && lo[V] - 1e-6 <= oo[V] && oo[V] <= hi[V] + 1e-6;
+		left = left || (origin_in_root && in_uv && lo[A] - 1e-6 <= oo[A] && oo[A] <= split + 1e-6);
+		right = right || (origin_in_root && in_uv && split - 1e-6 <= oo[A] && oo[A] <= hi[A] + 1e-6);
+	}
+}
+
+// Evaluated by every lane of the wave, whether or not it takes part in the visit (`mask`): the instructions cost the same, there is
+// no branch, and the answers are wave-uniform ballots the caller restricts to the visit's lanes.
+HXR_DEV void kd_children_hit(const Box& b, int axis, double split, d3 o, d3 inv, bool origin_in_root, unsigned long long mask, bool& left, bool& right)
+{
+	// `axis` is wave-uniform: three straight-line copies, no selects
+	if (axis == 0) kd_children_hit_axis<0>(b, split, o, inv, origin_in_root, mask, left, right);
+	else if (axis == 1) kd_children_hit_axis<1>(b, split, o, inv, origin_in_root, mask, left, right);
+	else kd_children_hit_axis<2>(b, split, o, inv, origin_in_root, mask, left, right);
 }
 
 // Mesh::intersect (src/mesh.cpp:247-263) as a PACKET walk of the reference's kd-tree.
@@ -633,15 +704,20 @@ HXR_DEV bool leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, in
 //     left(for the left-first lanes), right(for everybody), left(for the right-first lanes), so each lane still
 //     sees its own near child before its own far child;
 //   * a lane that finds a hit inside its leaf's box leaves the search, exactly like the reference's `return true`.
+// Round 3: a node's two children are box-tested TOGETHER when the node is entered (kd_children_hit: five of the six wall distances
+// are shared), for every lane of the visit.  The reference tests the far child's box only when the near subtree has come back
+// empty-handed, but the test has no side effect: making it early changes nothing a lane can observe, a lane that leaves the search in
+// the near subtree simply never uses its answer.  What is queued is therefore a visit together with the lanes that PASSED the node's
+// box; a child nobody reaches is not queued at all, and a visit that resumes from the stack needs no box test (the old walk popped a
+// node, loaded its box, tested it and -- for half of them -- found that no lane reached it).
 // Node records are the same for all lanes of a step, so they are fetched by scalar loads into SGPRs -- both
-// children of a binary node at once (they are adjacent, 128 B), as soon as the node is entered, because the
-// next box test is always against one of them; per-lane state is just the ray and its best hit.  The work
-// counters are per lane and equal the reference's per-ray counts (a box test is counted for a lane only when
-// that lane's own traversal makes it).
+// children of a binary node at once (they are adjacent, 32 B), as soon as the node is entered; per-lane state is just the ray and
+// its best hit.  The work counters are per lane and equal the reference's per-ray counts: a lane's test of its NEAR child is
+// counted when the node is entered, that of its FAR child when that child's turn comes and the lane is still searching (`due`
+// masks, instrumented builds only) -- exactly when the reference makes it.
 template <bool COUNT>
 HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, const Stacks& st, Tally<COUNT>& tl)
 {
-	const unsigned long long me = 1ull << (threadIdx.x & 63);
 	tl.template lap<PH_QUERY>();
 	const HxrKdSlim* kd = S.kd + M.kd_first;
 	const HxrKdBox* kd_box = S.kd_box + M.kd_first;
@@ -655,11 +731,12 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	if (!alive) { tl.template lap<PH_MESH>(); return false; }
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
-		leaf_query<COUNT>(S, M, 0, M.num_triangles, in_root, everything, o, d, nd, g, st, tl);
+		leaf_query<COUNT>(S, M, 0, M.num_triangles, alive, everything, o, d, nd, g, tl);
 		tl.template lap<PH_MESH>();
 		return in_root && g.t < HXR_INF;
 	}
-	bool found = false;
+	const bool origin_in_root = !M.boxes_nested || box_holds(cb, o);
+	unsigned long long found = 0;
 	int sp = 0;
 	unsigned long long mask = alive;   // lanes taking part in the visit of the current node
 	if (in_root) tl.add(HC_KD);
@@ -672,74 +749,82 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) atomicAdd(S.dev_stats + 5, 1ull);   // walk steps
 #endif
 		if (axis == HXR_KD_LEAF) {
-			bool here = leaf_query<COUNT>(S, M, R.first, ac >> 2, (mask & me) != 0, cb, o, d, nd, g, st, tl);
-			found = found || here;
-			alive &= ~hxr_ballot(here);
+			const unsigned long long here = leaf_query<COUNT>(S, M, R.first, ac >> 2, mask, cb, o, d, nd, g, tl);
+			found |= here;
+			alive &= ~here;
 		} else {
 			const double split = R.split;
 			const int left = R.first;
-			const HxrKdPair kids = *(const HxrKdPair*)(kd + left);   // in flight while the first child's box is being tested
-			unsigned long long rm = hxr_ballot(comp(o, axis) > split) & mask, lm = mask & ~rm;   // lanes whose near child is the right one
-			// the visits of this node's children, in execution order: the first one directly (its box derives from
-			// this node's, no load needed), the others through the stack
-			const bool go_left = lm != 0;
-			const unsigned long long next_mask = go_left ? lm : rm;
-			if (lm && rm) {
-				st.wave->node[sp] = left; st.wave->mask_lo[sp] = (uint32_t)rm; st.wave->mask_hi[sp] = (uint32_t)(rm >> 32); sp++;
-				st.wave->node[sp] = left + 1; st.wave->mask_lo[sp] = (uint32_t)mask; st.wave->mask_hi[sp] = (uint32_t)(mask >> 32); sp++;
-			} else {
-				st.wave->node[sp] = go_left ? left + 1 : left; st.wave->mask_lo[sp] = (uint32_t)next_mask; st.wave->mask_hi[sp] = (uint32_t)(next_mask >> 32); sp++;
+			const HxrKdPair kids = *(const HxrKdPair*)(kd + left);   // in flight while the children's boxes are being tested
+			bool pl, pr;
+			kd_children_hit(cb, axis, split, o, inv, origin_in_root, mask, pl, pr);
+			// lanes of the visit that reach the left / right child, and those whose near child is the right one
+			const unsigned long long ml = hxr_ballot(pl) & mask, mr = hxr_ballot(pr) & mask, rm = hxr_ballot(comp(o, axis) > split) & mask;
+			if (COUNT && __builtin_amdgcn_inverse_ballot_w64(mask)) tl.add(HC_BBOX);   // the near child's test; the far child's is counted when its turn comes
+			const unsigned long long lm = mask & ~rm;
+			// the visits of this node's children in execution order: left for the left-first lanes, right for everybody, left for the
+			// right-first lanes -- each with the lanes that pass the child's box
+			const unsigned long long v0 = lm & ml, v1 = mask & mr, v2 = rm & ml;
+			const int first = v0 ? 0 : (v1 ? 1 : (v2 ? 2 : 3));
+			if (COUNT) {   // far-child tests whose turn is NOW: those of the visit entered directly and of the empty visits before it
+				const unsigned long long now_due = (first >= 1 ? lm : 0ull) | (first >= 2 ? rm : 0ull);
+				if (__builtin_amdgcn_inverse_ballot_w64(now_due)) tl.add(HC_BBOX);
 			}
-			// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
-			const int moved = go_left ? axis : axis + 3;   // which of the six bounds becomes the split position
-			Box nb;
-			nb.hi.x = moved == 0 ? split : cb.hi.x;
-			nb.hi.y = moved == 1 ? split : cb.hi.y;
-			nb.hi.z = moved == 2 ? split : cb.hi.z;
-			nb.lo.x = moved == 3 ? split : cb.lo.x;
-			nb.lo.y = moved == 4 ? split : cb.lo.y;
-			nb.lo.z = moved == 5 ? split : cb.lo.z;
-			// first child of the node just entered: nobody has found anything since `mask` was formed
-			bool pass = false;
-			if (next_mask & me) {
-				pass = box_test<COUNT>(nb, o, d, inv, tl);
-				if (pass) tl.add(HC_KD);
+			// later visits wait on the stack, last one first
+			if (first < 2 && (v2 || (COUNT && rm))) {
+				st.wave->node[sp] = left; st.wave->mask_lo[sp] = (uint32_t)v2; st.wave->mask_hi[sp] = (uint32_t)(v2 >> 32);
+				if (COUNT) { st.wave->due_lo[sp] = (uint32_t)rm; st.wave->due_hi[sp] = (uint32_t)(rm >> 32); }
+				sp++;
 			}
-			unsigned long long m2 = hxr_ballot(pass);
-			if (m2) {
+			if (first < 1 && (v1 || (COUNT && lm))) {
+				st.wave->node[sp] = left + 1; st.wave->mask_lo[sp] = (uint32_t)v1; st.wave->mask_hi[sp] = (uint32_t)(v1 >> 32);
+				if (COUNT) { st.wave->due_lo[sp] = (uint32_t)lm; st.wave->due_hi[sp] = (uint32_t)(lm >> 32); }
+				sp++;
+			}
+			if (first < 3) {
+				// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
+				const bool go_left = first != 1;
+				const int moved = go_left ? axis : axis + 3;   // which of the six bounds becomes the split position
+				cb.hi.x = moved == 0 ? split : cb.hi.x;
+				cb.hi.y = moved == 1 ? split : cb.hi.y;
+				cb.hi.z = moved == 2 ? split : cb.hi.z;
+				cb.lo.x = moved == 3 ? split : cb.lo.x;
+				cb.lo.y = moved == 4 ? split : cb.lo.y;
+				cb.lo.z = moved == 5 ? split : cb.lo.z;
 				R = go_left ? kids.kid[0] : kids.kid[1];
-				cb = nb;
-				mask = m2;
+				mask = first == 0 ? v0 : (first == 1 ? v1 : v2);
+				if (COUNT && __builtin_amdgcn_inverse_ballot_w64(mask)) tl.add(HC_KD);
 				descended = true;
 			}
+#ifdef HXR_WALK_STATS   // developer aid: [0] nodes whose first visit is entered directly, [1] pops, [2] pops nobody waits for any more, [4] inner nodes none of whose children is reached, [5] inner nodes
+			if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) { atomicAdd(S.dev_stats + (first < 3 ? 0 : 4), 1ull); atomicAdd(S.dev_stats + 5, 1ull); }
+#endif
 		}
-		// otherwise the next pending visit whose lanes are still searching and whose box at least one of them reaches
+		// otherwise the next pending visit some of whose lanes are still searching
 		while (!descended && sp > 0) {
 			sp--;
-			int cn = __builtin_amdgcn_readfirstlane(st.wave->node[sp]);
-			unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.wave->mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.wave->mask_lo[sp]);
-			unsigned long long m = pm & alive;
+			const int cn = __builtin_amdgcn_readfirstlane(st.wave->node[sp]);
+			const unsigned long long pm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.wave->mask_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.wave->mask_lo[sp]);
+			if (COUNT) {
+				const unsigned long long due = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(st.wave->due_hi[sp]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(st.wave->due_lo[sp]);
+				if (__builtin_amdgcn_inverse_ballot_w64(due & alive)) tl.add(HC_BBOX);
+			}
+			const unsigned long long m = pm & alive;
+#ifdef HXR_WALK_STATS
+			if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) { atomicAdd(S.dev_stats + 1, 1ull); if (!m) atomicAdd(S.dev_stats + 2, 1ull); }
+#endif
 			if (!m) continue;
-			HxrKdSlim C = kd[cn];
-			HxrKdBox CB = kd_box[cn];
-			Box pb{ld3(CB.lo), ld3(CB.hi)};
-			bool pass = false;
-			if (m & me) {
-				pass = box_test<COUNT>(pb, o, d, inv, tl);
-				if (pass) tl.add(HC_KD);
-			}
-			unsigned long long m2 = hxr_ballot(pass);
-			if (m2) {
-				R = C;
-				cb = pb;
-				mask = m2;
-				descended = true;
-			}
+			R = kd[cn];
+			const HxrKdBox CB = kd_box[cn];
+			cb = Box{ld3(CB.lo), ld3(CB.hi)};
+			mask = m;
+			if (COUNT && __builtin_amdgcn_inverse_ballot_w64(m)) tl.add(HC_KD);
+			descended = true;
 		}
 		if (!descended) break;
 	}
 	tl.template lap<PH_MESH>();
-	return found;
+	return __builtin_amdgcn_inverse_ballot_w64(found);
 }
 
 // Mesh::intersect (src/mesh.cpp:247-263) walked by each lane for its own ray: the reference's recursion
@@ -759,14 +844,13 @@ HXR_DEV bool mesh_query_lane(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3
 	g.t = HXR_INF;
 	g.tri = -1;
 	if (!box_test<COUNT>(cb, o, d, inv, tl)) return false;
-	const HxrTriHot* hot = S.hot + M.hot_first;
-	const int32_t* ids = S.hot_ids + M.hot_first;
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		const Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
 		for (int i = 0; i < M.num_triangles; i++) {
 			tl.add(HC_TRI);
 			tl.add(HC_LEAFIDX);
-			triangle_test(M, hot[i], ids[i], everything, o, d, nd, g);
+			if (M.backface_culling) triangle_test<true>(S, M, S.hot[M.hot_first + i], M.hot_first + i, everything, o, d, nd, g);
+			else triangle_test<false>(S, M, S.hot[M.hot_first + i], M.hot_first + i, everything, o, d, nd, g);
 		}
 		return g.t < HXR_INF;
 	}
@@ -782,7 +866,8 @@ HXR_DEV bool mesh_query_lane(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3
 			for (int i = 0; i < count; i++) {
 				tl.add(HC_TRI);
 				tl.add(HC_LEAFIDX);
-				if (triangle_test(M, hot[first + i], ids[first + i], cb, o, d, nd, g)) found = true;
+				const int hi_ = M.hot_first + first + i;
+				if (M.backface_culling ? triangle_test<true>(S, M, S.hot[hi_], hi_, cb, o, d, nd, g) : triangle_test<false>(S, M, S.hot[hi_], hi_, cb, o, d, nd, g)) found = true;
 			}
 			if (found) return true;
 		} else {
@@ -1122,11 +1207,17 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 		}
 		case HXR_GEOM_MESH: if constexpr ((F & HXR_F_MESH) != 0) {   // Mesh::intersectTriangle's attribute half, src/mesh.cpp:196-218
 			const HxrMeshDev& M = S.meshes[N.ref];
-			const HXR_GLOBAL hxr_triangle& t = in_hbm(M.tris)[g.tri];
+			// the accepted hit: its hot record gives the barycentrics again (the products and the reciprocal of the test, tri_products),
+			// its entry of hot_ids the triangle
+			const HXR_GLOBAL HxrTriHot& hr = in_hbm(S.hot)[g.tri];
+			double Dcr, ga, gb, gc;
+			tri_products(ld3(hr.N), ld3(hr.A), ld3(hr.AB), ld3(hr.AC), ol, -dl, Dcr, ga, gb, gc);
+			const double rD = 1 / Dcr, hit_l2 = gb * rD, hit_l3 = gc * rD;
+			const HXR_GLOBAL hxr_triangle& t = in_hbm(M.tris)[in_hbm(S.hot_ids)[g.tri]];
 			const HXR_GLOBAL double* uvs = in_hbm(M.uvs);
 			tl.add(HC_MESHHIT);
 			d3 tA = ld3(uvs + 3 * (size_t)t.t[0]), tB = ld3(uvs + 3 * (size_t)t.t[1]), tC = ld3(uvs + 3 * (size_t)t.t[2]);
-			d3 tc = tA + (tB - tA) * g.l2 + (tC - tA) * g.l3;
+			d3 tc = tA + (tB - tA) * hit_l2 + (tC - tA) * hit_l3;
 			sf.u = tc.x;
 			sf.v = tc.y;
 			if (M.faceted) {
@@ -1134,7 +1225,7 @@ HXR_DEVX void surface_of(const HxrSceneDev& S, int ni, d3 o, d3 d, const GeomHit
 			} else {
 				const HXR_GLOBAL double* ns = in_hbm(M.normals);
 				d3 nA = ld3(ns + 3 * (size_t)t.n[0]), nB = ld3(ns + 3 * (size_t)t.n[1]), nC = ld3(ns + 3 * (size_t)t.n[2]);
-				n = unit(nA + (nB - nA) * g.l2 + (nC - nA) * g.l3);
+				n = unit(nA + (nB - nA) * hit_l2 + (nC - nA) * hit_l3);
 			}
 			sf.dNdx = ld3(t.dNdx);
 			sf.dNdy = ld3(t.dNdy);
@@ -1342,7 +1433,7 @@ HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any
 	int node = -1;
 	bw = limit;
 #ifdef HXR_STUB_QUERY   // developer aid: measure the integrator's own register footprint
-	if (o.x * d.y > limit) { bw = o.z; bg.t = d.x; bg.l2 = d.y; bg.l3 = d.z; bg.tri = (int)o.y; return 0; }
+	if (o.x * d.y > limit) { bw = o.z; bg.t = d.x; bg.tri = (int)o.y; return 0; }
 	return -1;
 #endif
 	for (int ni = 0; ni < S.num_nodes; ni++) {
@@ -2194,7 +2285,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 				if (P.tile_done) {
 					const unsigned long long wrote = hxr_ballot(live);
 					if (wrote && lane == (int)__builtin_ctzll(wrote)) {
-						__threadfence();
+						__threadfence_system();   // the reader is a copy engine on another stream: outside this agent
 						atomicAdd(P.tile_done + q / (uint32_t)(P.tile_size * P.tile_size), (uint32_t)__popcll(wrote));
 					}
 				}
@@ -2285,7 +2376,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		if (P.tile_done && in_tile) {   // progress for hxr_render's callback: the pixels of a packet lie in one tile
 			const unsigned long long wrote = hxr_ballot(live && sub == lanes_per_pixel - 1);
 			if (wrote && lane == (int)__builtin_ctzll(wrote)) {
-				__threadfence();   // the pixel stores before the count
+				__threadfence_system();   // the pixel stores before the count; system scope: the tile is read by a host-initiated copy on another stream while this kernel runs
 				atomicAdd(P.tile_done + q / (uint32_t)(P.tile_size * P.tile_size), (uint32_t)__popcll(wrote));
 			}
 		}

@@ -19,6 +19,9 @@ void HeightfieldData::build(Image& bmp, double blur, bool maxima_tables, bool ra
 			for (int x = 0; x < W; x++) heights[size_t(y) * W + x] = bmp.intensity(x, y);
 		if (blur > 0) {
 			blur_radius = std::min(128, int(std::floor(float(3 * blur) + 0.5f)));
+			// 0 < blur < 1/6: the radius rounds to 0, the reference's tap loops (src/heightfield.cpp:204-212) are empty and every height
+			// becomes 0 -- not "no blur", which is what a radius of 0 means to the module.  Flatten the field here.
+			if (blur_radius == 0) std::fill(heights.begin(), heights.end(), 0.0f);
 			blur_kernel.resize(size_t(blur_radius) * blur_radius);
 			for (int y = 0; y < blur_radius; y++)
 				for (int x = 0; x < blur_radius; x++)

@@ -141,6 +141,8 @@ void decode_gamma(Image& img, float gamma)
 	float key[256], val[256];
 	for (int q = 0; q < 256; q++) key[q] = val[q] = q / 255.0f;
 	for (float c : img.rgb) {
+		// range first: converting a NaN, an infinity or a huge texel of a float source to int is undefined behaviour
+		if (!(c >= 0.0f && c <= 1.0f)) { decode_span(img.rgb.data(), img.rgb.size(), srgb, gamma); return; }
 		const int q = (int)(c * 255.0f + 0.5f);
 		if (!(q >= 0 && q < 256 && key[q] == c)) { decode_span(img.rgb.data(), img.rgb.size(), srgb, gamma); return; }
 	}

@@ -117,3 +117,42 @@ def test_two_rank_gather_reassembles_the_frame(tmp_path):
     mp.spawn(_rank_main, args=(world, _free_port(), w, h, tile, out), nprocs=world, join=True)
     frame, full = np.load(out)
     assert np.array_equal(frame, full)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) must start N ranks itself, as its FIRST action, and report the number
+    of ranks that joined; under a launcher (WORLD_SIZE set) it must not launch again.  --rendezvous-check stops before any GPU work."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = os.environ.pop("WORLD_SIZE", None)
+    try:
+        args = bench.parse_args(["--gpus", "4", "--steps", "2"])
+        cmd = bench.launch_command(args, ["--gpus", "4", "--steps", "2"], 29999)
+        assert cmd is not None and cmd[1:3] == ["-m", "torch.distributed.run"]
+        assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+        assert bench.launch_command(bench.parse_args(["--gpus", "1"]), [], 0) is None
+        os.environ["WORLD_SIZE"] = "4"
+        assert bench.launch_command(args, [], 0) is None          # already a rank: the driver's torch.distributed.run form
+    finally:
+        os.environ.pop("WORLD_SIZE", None)
+        if saved is not None:
+            os.environ["WORLD_SIZE"] = saved
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"rendezvous_check": True, "n_gpus": 2, "asked": 2}
+    assert "starting the ranks" in r.stderr
+    # a rank count that does not match --gpus is refused, not reported
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-check"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "ranks joined" in (r.stderr + r.stdout)

@@ -75,6 +75,32 @@ def test_progress_callback_hands_over_finished_tiles(gpu):
     ds.close()
 
 
+def test_watched_frames_back_to_back_after_a_camera_move(gpu):
+    """Two watched frames in a row with different cameras: the per-tile progress words of the first frame (every tile complete) must not
+    be what the second frame's poll reads -- the clear is ordered before the first look (hxr_api.hip, "Watched frame") -- so every
+    tile handed over during the second frame already holds the SECOND camera's pixels."""
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(640, 360, dof=True, num_samples=16))
+    ds = hx.DeviceScene(hs)
+    p = hx.frame_params(tile_size=32)
+    for step in range(3):
+        if step:
+            hs.move_camera(1.5 * step, 0.7)
+            hs.rotate_camera(-6.0 * step, 2.0)
+            ds.update_camera()
+        final = ds.render(p)
+        out = np.full((360, 640, 3), -1.0, dtype=np.float32)
+        bad = []
+
+        def on_tile(x0, y0, x1, y1):
+            if not np.array_equal(out[y0:y1, x0:x1], final[y0:y1, x0:x1]):
+                bad.append((x0, y0))
+
+        got = ds.render(p, on_tile=on_tile, out=out)
+        assert not bad, (step, bad[:4])
+        assert np.array_equal(got, final)
+    ds.close()
+
+
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
 def test_device_group_equals_single_device(gpu, devices):
     """hxr_group_*: the C-level one-process multi-GPU driver.  This box has one GPU, so the group lists it several times (every
@@ -93,6 +119,8 @@ def test_device_group_equals_single_device(gpu, devices):
         assert len(tiles) == ((whole.shape[1] + 7) // 8) * ((whole.shape[0] + 7) // 8)
         with pytest.raises(hx.Cancelled):
             grp.render(hx.frame_params(**fp), cancel=ctypes.c_int(1))
+        # hxr_group_create leaves the process-wide device selection as it found it: a plain scene created afterwards renders the same frame
+        assert np.array_equal(hx.DeviceScene(hs).render(hx.frame_params(**fp)), whole)
         grp.close()
 
 

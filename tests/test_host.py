@@ -250,3 +250,19 @@ def test_loader_can_leave_the_kd_trees_to_the_render_module():
     for i in range(a.num_meshes):
         assert b.meshes[i].has_kd == a.meshes[i].has_kd and b.meshes[i].num_kd_nodes == 0
         assert list(b.meshes[i].bbox_min) == list(a.meshes[i].bbox_min) and list(b.meshes[i].bbox_max) == list(a.meshes[i].bbox_max)
+
+
+def test_heightfield_blur_below_one_sixth_flattens_the_field_on_both_paths():
+    """0 < blur < 1/6: nearestInt(3 * blur) is 0, the reference's tap loops (src/heightfield.cpp:204-212) are empty and every height becomes
+    0.  The host-prepared tables reproduce that; the raw-image descriptor (blur left to the module, where a radius of 0 means "no blur")
+    must hand over the same flat field."""
+    ov = "Heightfield island {\n\tblur 0.1\n}\n"
+    full = hx.HostScene(scene_path("heightfield.hexray"), ov)
+    raw = hx.HostScene(scene_path("heightfield.hexray"), ov, gpu_heightfield_blur=True)
+    for hs in (full, raw):
+        d = desc_of(hs)
+        f = d.heightfields[0]
+        n = f.W * f.H
+        heights = np.ctypeslib.as_array(d.f32_pool, shape=(d.f32_pool_size,))[f.first_height:f.first_height + n]
+        assert not heights.any()
+    assert desc_of(raw).heightfields[0].raw_heights == 1 and desc_of(raw).heightfields[0].blur_radius == 0
