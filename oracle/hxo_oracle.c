@@ -71,7 +71,18 @@ typedef struct {
 	   reference's shading.cpp is linked against in oracle/ref_harness_shading.cpp */
 	double* probe_rays; /* 8 doubles per recorded ray: start, dir, depth, flags */
 	int probe_max, probe_count, probe_on;
+	/* ... and visible() calls are recorded and answered from a pattern, draws come from a list (hxo_shade_probe2: the recording
+	   visible() and the recorded generator of `ref_harness_shading diffuse`) */
+	uint64_t probe_vis_pattern;
+	double* probe_vis_points; /* 6 doubles per recorded call: A, B */
+	int probe_vis_max, probe_vis_count;
+	const double* probe_draws; /* the numbers randDouble() handed out, in order; NULL = the counter-based generator */
+	int probe_draws_len, probe_draws_used;
 } ctx_t;
+
+/* two uniform draws: from the probe's list when there is one (unit-level tests replay the reference generator's numbers), else from the
+   counter-based generator under the given key / dimension */
+static inline void draw2(ctx_t* cx, uint32_t key, uint32_t dim, double* u, double* v);
 
 /* ------------------------------------------------------------------ vector / colour helpers */
 static inline vec V(double x, double y, double z) { vec r = {x, y, z}; return r; }
@@ -725,6 +736,14 @@ static col trace_ray(ctx_t* cx, const ray_t* ray);
 static int visible(ctx_t* cx, vec A, vec B)
 {
 	cx->cnt.shadow_queries++;
+	if (cx->probe_on) { /* unit-level probing: record the two points, answer with the bit the reference harness's visible() answers */
+		int k = cx->probe_vis_count++;
+		if (cx->probe_vis_points && k < cx->probe_vis_max) {
+			double* q = cx->probe_vis_points + 6 * k;
+			q[0] = A.x; q[1] = A.y; q[2] = A.z; q[3] = B.x; q[4] = B.y; q[5] = B.z;
+		}
+		return (int)((cx->probe_vis_pattern >> (k & 63)) & 1u);
+	}
 	double D = vdist(A, B);
 	ray_t ray;
 	memset(&ray, 0, sizeof ray);
@@ -777,6 +796,17 @@ static int raycast(ctx_t* cx, const ray_t* ray, hit_t* best, int* best_node, col
 	return 0;
 }
 
+static inline void draw2(ctx_t* cx, uint32_t key, uint32_t dim, double* u, double* v)
+{
+	if (cx->probe_draws) {
+		*u = cx->probe_draws_used < cx->probe_draws_len ? cx->probe_draws[cx->probe_draws_used] : 0.5;
+		*v = cx->probe_draws_used + 1 < cx->probe_draws_len ? cx->probe_draws[cx->probe_draws_used + 1] : 0.5;
+		cx->probe_draws_used += 2;
+		return;
+	}
+	hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, key, dim), u, v);
+}
+
 /* getLambertTerm, src/shading.cpp:57-65 */
 static float lambert_term(const hit_t* h, double* dist2, vec light_pos)
 {
@@ -799,8 +829,7 @@ static col shade_diffuse(ctx_t* cx, const hxr_shader* s, const ray_t* ray, const
 		col sum = C(0, 0, 0);
 		for (int i = 0; i < n; i++) {
 			double j1 = 0, j2 = 0;
-			if (L->type == HXR_LIGHT_RECT)
-				hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, ray->key, 0x10000u + (uint32_t)li * 4096u + (uint32_t)i), &j1, &j2);
+			if (L->type == HXR_LIGHT_RECT) draw2(cx, ray->key, 0x10000u + (uint32_t)li * 4096u + (uint32_t)i, &j1, &j2);
 			vec lp;
 			col lc;
 			light_sample(L, i, h->ip, j1, j2, &lp, &lc);
@@ -992,7 +1021,7 @@ static void brdf_spawn(ctx_t* cx, int si, const hit_t* h, const ray_t* in, ray_t
 			vec N = vfaceforward(w_in, h->norm);
 			out->start = vadd(h->ip, vmul(N, 1e-6));
 			double u, v;
-			hxo_uniform2(hxo_philox(cx->seed, cx->pixel, cx->sample, in->key, 2), &u, &v);
+			draw2(cx, in->key, 2, &u, &v);
 			out->dir = hemisphere(u, v, N);
 			out->flags |= RF_GI_DIFFUSE;
 			col base = s->texture >= 0 ? texture_sample(cx, s->texture, w_in, h) : cld(s->color);
@@ -1505,6 +1534,34 @@ int hxo_shade_probe(const hxr_scene_desc* sc, int shader, const double* start, c
 	return cx.probe_count;
 }
 
+/* hxo_shade_probe with the hooks Lambert / Phong need: visible() answers bit k of `vis_pattern` for the k-th call and records its two
+   points (vis_points[6 * k], up to max_vis; *n_vis = calls made), RectLight jitter is taken from `draws` (two per light sample, in
+   call order; *draws_used = numbers consumed) */
+int hxo_shade_probe2(const hxr_scene_desc* sc, int shader, const double* start, const double* dir, int depth, unsigned flags, const hxo_probe_hit* hit, float* out3,
+                     double* rays, int max_rays, uint64_t vis_pattern, double* vis_points, int max_vis, int* n_vis, const double* draws, int n_draws, int* draws_used)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	cx.probe_on = 1;
+	cx.probe_rays = rays;
+	cx.probe_max = max_rays;
+	cx.probe_vis_pattern = vis_pattern;
+	cx.probe_vis_points = vis_points;
+	cx.probe_vis_max = max_vis;
+	cx.probe_draws = draws;
+	cx.probe_draws_len = n_draws;
+	ray_t r;
+	memset(&r, 0, sizeof r);
+	r.start = vld(start); r.dir = vld(dir); r.depth = depth; r.flags = flags;
+	hit_t h = probe_hit(hit);
+	col c = shade(&cx, shader, &r, &h);
+	out3[0] = c.r; out3[1] = c.g; out3[2] = c.b;
+	if (n_vis) *n_vis = cx.probe_vis_count;
+	if (draws_used) *draws_used = cx.probe_draws_used;
+	return cx.probe_count;
+}
+
 void hxo_brdf_eval(const hxr_scene_desc* sc, int shader, const hxo_probe_hit* hit, const double* w_in, const double* w_out, float* out3)
 {
 	ctx_t cx;
@@ -1522,6 +1579,28 @@ void hxo_brdf_spawn(const hxr_scene_desc* sc, int shader, const hxo_probe_hit* h
 	ctx_t cx;
 	memset(&cx, 0, sizeof cx);
 	cx.sc = sc;
+	ray_t in, out;
+	memset(&in, 0, sizeof in);
+	in.start = vld(start); in.dir = vld(dir); in.depth = depth; in.flags = flags;
+	out = in;
+	hit_t h = probe_hit(hit);
+	col c;
+	brdf_spawn(&cx, shader, &h, &in, &out, &c, pdf);
+	out8[0] = out.start.x; out8[1] = out.start.y; out8[2] = out.start.z; out8[3] = out.dir.x; out8[4] = out.dir.y; out8[5] = out.dir.z;
+	out8[6] = out.depth; out8[7] = out.flags;
+	color3[0] = c.r; color3[1] = c.g; color3[2] = c.b;
+}
+
+/* hxo_brdf_spawn with the two draws of hemisphereSample handed in (Lambert::spawnRay) */
+void hxo_brdf_spawn2(const hxr_scene_desc* sc, int shader, const hxo_probe_hit* hit, const double* start, const double* dir, int depth, unsigned flags, double u, double v,
+                     double* out8, float* color3, float* pdf)
+{
+	ctx_t cx;
+	memset(&cx, 0, sizeof cx);
+	cx.sc = sc;
+	const double uv[2] = {u, v};
+	cx.probe_draws = uv;
+	cx.probe_draws_len = 2;
 	ray_t in, out;
 	memset(&in, 0, sizeof in);
 	in.start = vld(start); in.dir = vld(dir); in.depth = depth; in.flags = flags;

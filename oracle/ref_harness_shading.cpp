@@ -13,14 +13,24 @@
 // this program DOES reach is the reference's own machine code:
 //     CheckerTexture::sample, Fresnel::sample (+ fresnelSchlickApprox), Bumps::modifyNormal, ConstantShader / Const,
 //     Reflection::computeColor (mirror and glossy) / eval / spawnRay, Refraction::computeColor (+ refract) / eval / spawnRay,
-//     Layered::addLayer / computeColor, hemisphereSample, unitDiskSample, BBox::split.
+//     Layered::addLayer / computeColor, hemisphereSample, unitDiskSample, BBox::split;
+//     round 3: Lambert::computeColor / eval / spawnRay, Phong::computeColor (+ getLambertTerm), over PointLight / RectLight ::getNthSample.
 // What this program itself defines, because the reference declares it elsewhere:
 //   * `Color raytrace(const Ray&)` and `bool visible(...)` (src/main.h; defined in main.cpp, which needs SDL.h): shaders call them
 //     for their secondary rays.  Here raytrace() RECORDS the ray and answers with a colour that is a fixed function of its
 //     direction (the oracle's probe mode answers with the same function), so the test sees both the rays a shader asks for and
 //     what it does with the answer; visible() is never reached by the members above.
 //   * SceneElement's five trivial members (src/scene.cpp:53-59), as in ref_harness.cpp.
-// NOT pinned by any reference vector, and why: Lambert / Phong::computeColor, Lambert::eval / spawnRay (`Scene scene`);
+//   * round 3, for Lambert / Phong: the global `Scene scene` (src/scene.cpp:811) with Scene's two-line constructor (src/scene.cpp:724-728:
+//     two null pointers) and an EMPTY destructor (the reference's deletes the scene's elements, src/scene.cpp:730-733; the lights
+//     listed here live on the stack).  scene.h itself compiles (shading.h includes it).  GlobalSettings' vtable lives in scene.cpp
+//     (its key function fillProperties is defined there): it is left unresolved like the parser helpers above -- no virtual call is
+//     ever made on `scene.settings`, only its ambientLight field is read.  The lights are the reference's own PointLight / RectLight
+//     (lights.cpp is linked), configured through their fillProperties; visible() (src/main.h) RECORDS its two points and answers
+//     with bit k of a per-case pattern for the k-th call of the case.  `ref_harness_shading diffuse` prints these sections (a
+//     process of its own: the samplers' generator starts from its default seed, so the draws of RectLight::getNthSample and
+//     hemisphereSample can be recorded from a twin engine advanced in lockstep, two per call).
+// NOT pinned by any reference vector, and why:
 // BitmapTexture::sample, BumpTexture::modifyNormal, CubemapEnvironment::getEnvironment, Heightfield (Bitmap -> OpenEXR);
 // Mesh::intersectTriangle / intersectKD / buildKD and BBox::intersectTriangle (it calls intersectTriangleFast, defined in mesh.cpp,
 // which includes SDL.h); Camera (sdl.h); the render loops of main.cpp.
@@ -32,9 +42,13 @@
 #include <string>
 #include <vector>
 
+#include <map>
+
 #include "bbox.h"
 #include "color.h"
+#include "lights.h"
 #include "main.h"
+#include "scene.h"
 #include "shading.h"
 #include "util.h"
 
@@ -50,7 +64,21 @@ Color raytrace(const Ray& ray)
 	recorded.push_back(ray);
 	return Color(float(0.2 + 0.6 * fabs(ray.dir.x)), float(0.2 + 0.6 * fabs(ray.dir.y)), float(0.2 + 0.6 * fabs(ray.dir.z)));
 }
-bool visible(const Vector&, const Vector&) { return true; }
+// ---- the recording visible(): the k-th call of a case is answered with bit k of the case's pattern
+struct VisCall { Vector a, b; };
+static std::vector<VisCall> vis_calls;
+static unsigned long long vis_pattern = ~0ull;
+bool visible(const Vector& a, const Vector& b)
+{
+	bool answer = (vis_pattern >> (vis_calls.size() & 63)) & 1;
+	vis_calls.push_back(VisCall{a, b});
+	return answer;
+}
+
+// ---- the scene Lambert / Phong read their lights and the ambient term from (see the header)
+Scene::Scene() { environment = NULL; camera = NULL; }
+Scene::~Scene() {}
+Scene scene;
 
 // ---- deterministic inputs (harness-local generator; not the reference's)
 static std::mt19937_64 input_rng(20261005);
@@ -141,8 +169,141 @@ struct OneNumber : ParsedBlock {   // serves one float property (Bumps keeps its
 	SceneParser& getParser() override { return *(SceneParser*)nullptr; }
 };
 
-int main()
+struct LightBlock : OneNumber {   // serves a light's properties: colour / position vectors, numbers, a transform as a list of operations
+	std::map<std::string, Vector> vectors;
+	std::map<std::string, double> numbers;
+	std::vector<std::pair<std::string, Vector>> ops;
+	LightBlock() { key = ""; value = 0; }
+	bool getIntProp(const char* name, int* v, int, int) override { auto it = numbers.find(name); if (it == numbers.end()) return false; *v = int(it->second); return true; }
+	bool getFloatProp(const char* name, float* v, float, float) override { auto it = numbers.find(name); if (it == numbers.end()) return false; *v = float(it->second); return true; }
+	bool getDoubleProp(const char* name, double* v, double, double) override { auto it = numbers.find(name); if (it == numbers.end()) return false; *v = it->second; return true; }
+	bool getColorProp(const char* name, Color* v, float, float) override
+	{
+		auto it = vectors.find(name);
+		if (it == vectors.end()) return false;
+		*v = Color(float(it->second.x), float(it->second.y), float(it->second.z));
+		return true;
+	}
+	bool getVectorProp(const char* name, Vector* v) override { auto it = vectors.find(name); if (it == vectors.end()) return false; *v = it->second; return true; }
+	void getTransformProp(Transform& T) override
+	{
+		for (auto& op : ops) {
+			if (op.first == "scale") T.scale(op.second.x, op.second.y, op.second.z);
+			else if (op.first == "rotate") T.rotate(op.second.x, op.second.y, op.second.z);
+			else T.translate(op.second);
+		}
+	}
+};
+
+// Lambert / Phong (src/shading.cpp:57-145) over the reference's own lights.  Everything a case needs to be replayed is printed: the
+// lights as .hexray properties, the pattern visible() answered with, the two points of every visible() call, the generator's draws.
+static int diffuse_sections()
 {
+	printf("{\n\"_comment\": \"golden vectors produced by `oracle/ref_harness_shading diffuse` from the reference's own shading.cpp / lights.cpp / util.cpp\"");
+	first_in_scope = false;
+	std::mt19937 twin;   // same engine + default seed as `thread_local static std::mt19937 generator` (src/util.cpp:81), advanced in lockstep
+	std::uniform_real_distribution<double> twin_dist;
+	open_list("diffuse");
+	for (int i = 0; i < 256; i++) {
+		Case c = random_case(i);
+		const bool phong = i % 2;
+		Lambert lam;
+		Phong ph;
+		Lambert& sh = phong ? (Lambert&)ph : lam;
+		sh.diffuse = rand_color();
+		ph.specular = rand_color();
+		ph.exponent = float(uni(1, 120));
+		CheckerTexture ck;
+		ck.color1 = rand_color();
+		ck.color2 = rand_color();
+		ck.scaling = uni(0.5, 20);
+		const bool textured = i % 5 == 3;
+		if (textured) sh.diffuseTex = &ck;
+		scene.settings.ambientLight = rand_color() * 0.4f;
+		const int nl = 1 + i % 3;
+		std::vector<PointLight> points(nl);
+		RectLight rect;
+		const int rect_at = (i % 4 == 2) ? int(uni(0, nl)) : -1;   // which of the lights is the rectangle light, if any
+		scene.lights.clear();
+		std::string lights = "[", draws = "[";
+		int ndraws = 0;
+		for (int k = 0; k < nl; k++) {
+			LightBlock pb;
+			pb.vectors["color"] = Vector(uni(0, 1), uni(0, 1), uni(0, 1));
+			pb.numbers["power"] = uni(20, 4000);
+			if (i % 16 == 9 && k == 0) pb.vectors["color"] = Vector(0, 0, 0);   // a light whose samples are skipped (lightColor.isZero())
+			if (k == rect_at) {
+				pb.ops = {{"translate", c.info.ip + rand_dir() * uni(4, 30)}, {"rotate", Vector(uni(-180, 180), uni(-80, 80), uni(-180, 180))},
+				          {"scale", Vector(uni(1, 8), uni(1, 8), uni(1, 8))}};
+				pb.numbers["xSubd"] = 1 + int(uni(0, 3));
+				pb.numbers["ySubd"] = 1 + int(uni(0, 3));
+				rect.fillProperties(pb);
+				rect.beginFrame();
+				scene.lights.push_back(&rect);
+				std::string ops = "[";
+				for (size_t q = 0; q < pb.ops.size(); q++) ops += std::string(q ? "," : "") + "{\"op\":\"" + pb.ops[q].first + "\",\"v\":" + vec(pb.ops[q].second) + "}";
+				lights += std::string(k ? "," : "") + "{\"rect\":1,\"color\":" + vec(pb.vectors["color"]) + ",\"power\":" + num(float(pb.numbers["power"])) + ",\"ops\":" + ops +
+				          "],\"xSubd\":" + std::to_string(int(pb.numbers["xSubd"])) + ",\"ySubd\":" + std::to_string(int(pb.numbers["ySubd"])) + "}";
+				for (int q = 0; q < 2 * rect.getNumSamples(); q++) draws += std::string(ndraws++ ? "," : "") + num(twin_dist(twin));   // two randDouble() per sample
+			} else {
+				pb.vectors["pos"] = c.info.ip + rand_dir() * uni(3, 40);
+				points[k].fillProperties(pb);
+				scene.lights.push_back(&points[k]);
+				lights += std::string(k ? "," : "") + "{\"rect\":0,\"color\":" + vec(pb.vectors["color"]) + ",\"power\":" + num(float(pb.numbers["power"])) + ",\"pos\":" +
+				          vec(pb.vectors["pos"]) + "}";
+			}
+		}
+		lights += "]";
+		draws += "]";
+		vis_pattern = input_rng();
+		if (i % 8 == 0) vis_pattern = ~0ull;   // everything visible
+		vis_calls.clear();
+		Color out = sh.computeColor(c.ray, c.info);
+		std::string vis = "[";
+		for (size_t q = 0; q < vis_calls.size(); q++) vis += std::string(q ? "," : "") + "{\"a\":" + vec(vis_calls[q].a) + ",\"b\":" + vec(vis_calls[q].b) + "}";
+		vis += "]";
+		sep();
+		printf("{%s,\"phong\":%d,\"color\":%s,\"specular\":%s,\"exponent\":%s,\"textured\":%d,\"checker1\":%s,\"checker2\":%s,\"checker_scaling\":%s,\"ambient\":%s,"
+		       "\"lights\":%s,\"pattern\":\"%llu\",\"visible_calls\":%s,\"draws\":%s,\"out\":%s}",
+		       case_json(c).c_str(), phong ? 1 : 0, col(sh.diffuse).c_str(), col(ph.specular).c_str(), num(ph.exponent).c_str(), textured ? 1 : 0, col(ck.color1).c_str(),
+		       col(ck.color2).c_str(), num(ck.scaling).c_str(), col(scene.settings.ambientLight).c_str(), lights.c_str(), vis_pattern, vis.c_str(), draws.c_str(), col(out).c_str());
+		scene.lights.clear();
+	}
+	close_list();
+	// Lambert::eval / spawnRay (src/shading.cpp:93-109) as pathtrace() calls them; spawnRay draws two numbers (hemisphereSample)
+	open_list("diffuse_brdf");
+	for (int i = 0; i < 128; i++) {
+		Case c = random_case(i);
+		Lambert lam;
+		lam.diffuse = rand_color();
+		CheckerTexture ck;
+		ck.color1 = rand_color();
+		ck.color2 = rand_color();
+		ck.scaling = uni(0.5, 20);
+		const bool textured = i % 4 == 1;
+		if (textured) lam.diffuseTex = &ck;
+		Ray w_out = c.ray;
+		w_out.depth++;
+		Color bc;
+		float pdf = 0;
+		const double u = twin_dist(twin), v = twin_dist(twin);
+		lam.spawnRay(c.info, c.ray.dir, w_out, bc, pdf);
+		Vector other = rand_dir();
+		Color e = lam.eval(c.info, c.ray.dir, other);
+		sep();
+		printf("{%s,\"color\":%s,\"textured\":%d,\"checker1\":%s,\"checker2\":%s,\"checker_scaling\":%s,\"draw_u\":%s,\"draw_v\":%s,\"spawn_o\":%s,\"spawn_d\":%s,\"spawn_flags\":%u,"
+		       "\"spawn_color\":%s,\"pdf\":%s,\"other\":%s,\"eval_other\":%s}",
+		       case_json(c).c_str(), col(lam.diffuse).c_str(), textured ? 1 : 0, col(ck.color1).c_str(), col(ck.color2).c_str(), num(ck.scaling).c_str(), num(u).c_str(),
+		       num(v).c_str(), vec(w_out.start).c_str(), vec(w_out.dir).c_str(), w_out.flags, col(bc).c_str(), num(pdf).c_str(), vec(other).c_str(), col(e).c_str());
+	}
+	close_list();
+	printf("\n}\n");
+	return 0;
+}
+
+int main(int argc, char** argv)
+{
+	if (argc > 1 && !strcmp(argv[1], "diffuse")) return diffuse_sections();
 	printf("{\n\"_comment\": \"golden vectors produced by oracle/ref_harness_shading.cpp from the reference's own shading.cpp / util.cpp / bbox.h\"");
 	first_in_scope = false;
 

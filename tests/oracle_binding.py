@@ -53,6 +53,10 @@ def _load(path):
     lib.hxo_shade_probe.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_double), c_int, c_uint32, POINTER(ProbeHit), POINTER(c_float), POINTER(c_double), c_int]
     lib.hxo_brdf_eval.argtypes = [c_void_p, c_int, POINTER(ProbeHit), POINTER(c_double), POINTER(c_double), POINTER(c_float)]
     lib.hxo_brdf_spawn.argtypes = [c_void_p, c_int, POINTER(ProbeHit), POINTER(c_double), POINTER(c_double), c_int, c_uint32, POINTER(c_double), POINTER(c_float), POINTER(c_float)]
+    lib.hxo_shade_probe2.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_double), c_int, c_uint32, POINTER(ProbeHit), POINTER(c_float), POINTER(c_double), c_int,
+                                     c_uint64, POINTER(c_double), c_int, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_int)]
+    lib.hxo_brdf_spawn2.argtypes = [c_void_p, c_int, POINTER(ProbeHit), POINTER(c_double), POINTER(c_double), c_int, c_uint32, c_double, c_double, POINTER(c_double),
+                                    POINTER(c_float), POINTER(c_float)]
     return lib
 
 

@@ -205,3 +205,87 @@ def test_specular_brdfs(golden):
         for w_out, want in ((c["mirror"], c["eval_mirror"]), (c["other"], c["eval_other"])):
             lib.hxo_brdf_eval(hs.desc, 1 + i, ctypes.byref(h), dvec(*c["d"]), dvec(*w_out), ev)
             assert close(list(ev), want, F32), c
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Lambert / Phong (round 3): tests/golden/reference_diffuse_vectors.json is written by `oracle/ref_harness_shading diffuse`, where the
+# reference's own Lambert::computeColor / Phong::computeColor run over the reference's own PointLight / RectLight, a harness-owned
+# `Scene scene` (lights + ambientLight) and a visible() that records its two points and answers from a per-case bit pattern.
+@pytest.fixture(scope="module")
+def diffuse_golden():
+    with open(os.path.join(HERE, "golden", "reference_diffuse_vectors.json")) as f:
+        return json.load(f)
+
+
+def diffuse_scene_text(c, with_lights=True):
+    text = ""
+    if with_lights:
+        text += f"GlobalSettings {{\n\tambientLight {vec_text(c['ambient'])}\n}}\n"
+        for k, L in enumerate(c["lights"]):
+            if L["rect"]:
+                ops = "".join(f"\t{o['op']} {vec_text(o['v'])}\n" for o in L["ops"])
+                text += f"RectLight l{k} {{\n{ops}\tcolor {vec_text(L['color'])}\n\tpower {L['power']!r}\n\txSubd {L['xSubd']}\n\tySubd {L['ySubd']}\n}}\n"
+            else:
+                text += f"PointLight l{k} {{\n\tpos {vec_text(L['pos'])}\n\tcolor {vec_text(L['color'])}\n\tpower {L['power']!r}\n}}\n"
+    tex = ""
+    if c["textured"]:
+        text += f"CheckerTexture ck {{\n\tcolor1 {vec_text(c['checker1'])}\n\tcolor2 {vec_text(c['checker2'])}\n\tscaling {c['checker_scaling']!r}\n}}\n"
+        tex = "\ttexture ck\n"
+    if c.get("phong"):
+        text += f"Phong sh {{\n\tcolor {vec_text(c['color'])}\n\tspecular {vec_text(c['specular'])}\n\texponent {c['exponent']!r}\n{tex}}}\n"
+    else:
+        text += f"Lambert sh {{\n\tcolor {vec_text(c['color'])}\n{tex}}}\n"
+    return text
+
+
+def test_lambert_and_phong_against_the_reference(diffuse_golden):
+    """Lambert::computeColor / Phong::computeColor (reference src/shading.cpp:57-91,112-145): for every light and light sample the two
+    points handed to visible() (light sample position -- PointLight::pos or RectLight::getNthSample driven by the reference generator's
+    own draws -- and ip + norm * 1e-6), which samples are skipped (zero light colour, blocked), and the colour: diffuse + specular
+    terms, the division by the sample count, the ambient term."""
+    lib = oracle_lib()
+    kinds = {"phong": 0, "lambert": 0, "rect": 0, "blocked": 0, "skipped_lights": 0}
+    for c in diffuse_golden["diffuse"]:
+        hs = hx.HostScene(TINY, diffuse_scene_text(c))
+        d = desc_of(hs)
+        assert d.num_lights == len(c["lights"]) and d.num_shaders == 2
+        out = (ctypes.c_float * 3)()
+        max_vis = 64
+        pts = (ctypes.c_double * (6 * max_vis))()
+        n_vis, used = ctypes.c_int(), ctypes.c_int()
+        draws = (ctypes.c_double * max(1, len(c["draws"])))(*c["draws"])
+        n_rays = lib.hxo_shade_probe2(hs.desc, 1, dvec(*c["o"]), dvec(*c["d"]), c["depth"], c["flags"], ctypes.byref(hit_of(c)), out, None, 0,
+                                      int(c["pattern"]), pts, max_vis, ctypes.byref(n_vis), draws if c["draws"] else None, len(c["draws"]), ctypes.byref(used))
+        assert n_rays == 0                                                   # diffuse shaders trace nothing
+        assert n_vis.value == len(c["visible_calls"]), (n_vis.value, len(c["visible_calls"]), c["lights"])
+        for k, w in enumerate(c["visible_calls"]):
+            assert close(list(pts[6 * k:6 * k + 3]), w["a"], 1e-11, 1e-10), (k, c["lights"])          # light sample position
+            assert close(list(pts[6 * k + 3:6 * k + 6]), w["b"], 1e-12, 1e-12), k                      # ip + norm * 1e-6
+        # every draw is consumed only when visible() is reached or skipped by a zero colour: the reference draws in getNthSample, before either
+        assert used.value == len(c["draws"])
+        assert close(list(out), c["out"], 2e-5, 2e-6), (list(out), c["out"], c["lights"])
+        kinds["phong" if c["phong"] else "lambert"] += 1
+        kinds["rect"] += any(L["rect"] for L in c["lights"])
+        kinds["blocked"] += int(c["pattern"]) != 2 ** 64 - 1
+        samples = sum(L["xSubd"] * L["ySubd"] if L["rect"] else 1 for L in c["lights"])
+        kinds["skipped_lights"] += samples != len(c["visible_calls"])
+        hs.close()
+    assert min(kinds.values()) > 10, kinds
+
+
+def test_lambert_brdf_against_the_reference(diffuse_golden):
+    """Lambert::eval / spawnRay (reference src/shading.cpp:93-109) as pathtrace() calls them: origin offset along the faceforwarded
+    normal, the hemisphere direction made of the reference generator's own two draws, RF_GI_DIFFUSE, colour and pdf."""
+    lib = oracle_lib()
+    out8, col, pdf, ev = (ctypes.c_double * 8)(), (ctypes.c_float * 3)(), ctypes.c_float(), (ctypes.c_float * 3)()
+    for c in diffuse_golden["diffuse_brdf"]:
+        hs = hx.HostScene(TINY, diffuse_scene_text(c, with_lights=False))
+        h = hit_of(c)
+        lib.hxo_brdf_spawn2(hs.desc, 1, ctypes.byref(h), dvec(*c["o"]), dvec(*c["d"]), c["depth"] + 1, c["flags"], c["draw_u"], c["draw_v"], out8, col, ctypes.byref(pdf))
+        assert pdf.value == c["pdf"], c
+        assert close(list(out8[0:3]), c["spawn_o"], 1e-12, 1e-11) and close(list(out8[3:6]), c["spawn_d"], 1e-12, 1e-14), c
+        assert int(out8[6]) == c["depth"] + 1 and int(out8[7]) == c["spawn_flags"], c
+        assert close(list(col), c["spawn_color"], F32, 1e-9), c
+        lib.hxo_brdf_eval(hs.desc, 1, ctypes.byref(h), dvec(*c["d"]), dvec(*c["other"]), ev)
+        assert close(list(ev), c["eval_other"], F32, 1e-9), c
+        hs.close()
