@@ -583,7 +583,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 				else if (one_pending) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
 				else HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT, HXR_MESH_WAVES);
 				break;
-			case V_HEIGHTFIELD: HXR_LAUNCH_F(HXR_F_HEIGHTFIELD | HXR_F_REFRACT, HXR_HEIGHTFIELD_WAVES); break;
+			case V_HEIGHTFIELD: HXR_LAUNCH_F(HXR_HEIGHTFIELD_F, HXR_HEIGHTFIELD_WAVES); break;
 			case V_SPHERE_GI: HXR_LAUNCH_F(HXR_F_SPHERE | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, HXR_SPHERE_GI_WAVES); break;
 			case V_MESH_GI: HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, HXR_MESH_GI_WAVES); break;
 			case V_ALL_GI_3: HXR_LAUNCH_F(HXR_F_ALL, 3); break;

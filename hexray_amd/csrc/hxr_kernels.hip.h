@@ -57,8 +57,14 @@ enum : unsigned {
 	// levels deep inside two functions that are CALLED, not inlined: inlined into the flattened integrator they cost every catch-all
 	// kernel its register allocation (scratch 1 KB -> 15-29 KB per lane, kdtree_test 11.7 -> 80 ms), and as calls in the ordinary
 	// catch-alls they still cost 4x (the kernel then lives by the call ABI) -- so only scenes that nest CSG run these variants.
-	HXR_F_CSGNEST = 2048u
+	HXR_F_CSGNEST = 2048u,
+	// Whitted, in place: the first HXR_LDS_RAY_SLOTS entries of the per-lane ray stack live in LDS (18 dwords per entry and lane, a row of
+	// 64 lanes per dword), the rest -- reached only by hits stacked deeper than that -- in the scratch array as before.  For the variants
+	// compiled for two waves per SIMD, which leave the LDS of a CU idle (the heightfield variant: every water hit pushes a reflected and
+	// a refracted ray, 2.4 GB of scratch writes per frame before this).
+	HXR_F_LDSSTACK = 4096u
 };
+#define HXR_LDS_RAY_SLOTS 4   // 4 x 18 dwords x 256 lanes = 72 KB per block: two blocks per CU (2 waves per SIMD) fit the 160 KB
 
 // counters (COUNT builds only); order = hxr_counters
 enum {
@@ -562,6 +568,8 @@ HXR_DEV bool box_holds_eps(const Box& b, d3 p, double eps)
 // Mesh::intersectTriangle (src/mesh.cpp:178-195) against the running best hit `g`, and the leaf rule of Mesh::intersectKD
 // (src/mesh.cpp:228): returns true when the triangle is accepted AND its hit point lies in the leaf's box.  One definition for the
 // packet walk (record and index wave-uniform: scalar loads) and the per-lane walk (vector loads).  `hot` = the record's scene-wide index.
+HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, double gc, int hot, const Box& box, d3 o, d3 d, GeomHit& g);
+
 template <bool BACKFACE>
 HXR_DEV bool triangle_test(const HxrSceneDev& S, const HxrMeshDev& M, const HxrTriHot& T, int hot, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g)
 {
@@ -574,8 +582,14 @@ HXR_DEV bool triangle_test(const HxrSceneDev& S, const HxrMeshDev& M, const HxrT
 	// packet fail at different ones, so nested early-outs only add mask bookkeeping (8 levels of it).
 	double Dcr, ga, gb, gc;
 	tri_products(ld3(T.N), ld3(T.A), ld3(T.AB), ld3(T.AC), o, nd, Dcr, ga, gb, gc);
+	return triangle_decide(ok, Dcr, ga, gb, gc, hot, box, o, d, g);
+}
+
+// The rest of Mesh::intersectTriangle once the four products are known (see triangle_test); `facing`: not culled as a back face
+HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, double gc, int hot, const Box& box, d3 o, d3 d, GeomHit& g)
+{
 	const bool neg = Dcr < 0;
-	ok = ok & !(fabs(Dcr) < 1e-12)
+	bool ok = facing & !(fabs(Dcr) < 1e-12)
 	        & !(((ga < 0) != neg) & (ga != 0))    // gamma < 0
 	        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
 	        & !(((gc < 0) != neg) & (gc != 0));   // lambda3 < 0
@@ -1559,16 +1573,18 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 	constexpr bool rect = (F & HXR_F_RECT) != 0;   // RectLight code only where the scene has one
 	constexpr bool defer = (F & HXR_F_DEFER) != 0; // secondary rays go to the queue: `top` stays 0, the stack is never touched
 	constexpr bool one = (F & HXR_F_STACK1) != 0;  // at most one pending ray: it waits in LDS (st.pend)
+	constexpr int lds_slots = (F & HXR_F_LDSSTACK) != 0 ? HXR_LDS_RAY_SLOTS : 0;   // stack entries 0 .. lds_slots-1 live in LDS (st.pend), the rest in `stack`
+	static_assert(lds_slots == 0 || (!gi && !glossy && !defer && !one), "the LDS stack entries are for the in-place Whitted variants without glossy generators");
 	static_assert(!defer || (!gi && !glossy), "deferral is for the Whitted variants without glossy generators");
 	static_assert(!one || (!gi && !glossy && !defer), "the one-slot stack is for the in-place Whitted variants");
-	StackItem<glossy> stack[(defer || one) ? 1 : HXR_RAY_STACK];
+	StackItem<glossy> stack[(defer || one) ? 1 : HXR_RAY_STACK - lds_slots];
 	const int pend_lane = threadIdx.x & 63;
-	auto pend_store = [&](const RayItem& r) {   // HXR_F_STACK1: the pending ray, one LDS row per dword (conflict-free)
+	auto pend_store = [&](const RayItem& r, int slot = 0) {   // HXR_F_STACK1 / HXR_F_LDSSTACK: a pending ray, one LDS row per dword (conflict-free)
 #ifdef HXR_PEND_IN_REGS
 		stack[0].r = r;
 		return;
 #endif
-		uint32_t* p = st.pend + pend_lane;
+		uint32_t* p = st.pend + slot * (HXR_PEND_DWORDS * 64) + pend_lane;
 		const double v[6] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z};
 #pragma unroll
 		for (int k = 0; k < 6; k++) {
@@ -1583,11 +1599,11 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 		p[16 * 64] = r.flags;
 		p[17 * 64] = r.key;
 	};
-	auto pend_load = [&]() {
+	auto pend_load = [&](int slot = 0) {
 #ifdef HXR_PEND_IN_REGS
 		return stack[0].r;
 #endif
-		const uint32_t* p = st.pend + pend_lane;
+		const uint32_t* p = st.pend + slot * (HXR_PEND_DWORDS * 64) + pend_lane;
 		double v[6];
 #pragma unroll
 		for (int k = 0; k < 6; k++) v[k] = __builtin_bit_cast(double, ((unsigned long long)p[(2 * k + 1) * 64] << 32) | p[(2 * k) * 64]);
@@ -1606,7 +1622,14 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 			top = 0;
 			return;
 		}
-		StackItem<glossy>& e = stack[top - 1];
+		if constexpr (lds_slots > 0) {
+			if (top <= lds_slots) {
+				cur = pend_load(top - 1);
+				top--;
+				return;
+			}
+		}
+		StackItem<glossy>& e = stack[top - 1 - lds_slots];
 		if constexpr (glossy) {
 			if (e.left > 0) {
 				const hxr_shader& sh = S.shaders[e.shader];
@@ -1935,8 +1958,11 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 										pend_store(RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)});
 										top = 1;
 									}
+								} else if (lds_slots > 0 && top < lds_slots) {
+									pend_store(RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)}, top);
+									top++;
 								} else if (top < HXR_RAY_STACK) {
-									StackItem<glossy>& e = stack[top++];
+									StackItem<glossy>& e = stack[top++ - lds_slots];
 									e.r = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
 									if constexpr (glossy) {
 										e.left = 0;
@@ -1963,8 +1989,11 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 											pend_store(RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)});
 											top = 1;
 										}
+									} else if (ok && lds_slots > 0 && top < lds_slots) {
+										pend_store(RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)}, top);
+										top++;
 									} else if (ok && top < HXR_RAY_STACK) {
-										StackItem<glossy>& e = stack[top++];
+										StackItem<glossy>& e = stack[top++ - lds_slots];
 										e.r = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
 										if constexpr (glossy) e.left = 0;
 									}
@@ -2067,6 +2096,26 @@ HXR_DEV void morton6(uint32_t m, int& x, int& y)
 
 HXR_DEV bool shard_pixel(const HxrLaunch& P, uint32_t q, int& x, int& y)
 {
+	const int ts = P.tile_size;
+	// Tile size and pixels per packet both powers of two (the default 64 and the shards' 8; every power-of-two spp): shifts and masks, and ONE
+	// division, made once for the wave -- the pixels of such a packet lie in one tile.  (Three samples per pixel make packets of 21 pixels,
+	// which straddle tiles: they take the general path below.)
+	if ((ts & (ts - 1)) == 0 && (P.pixels_per_chunk & (P.pixels_per_chunk - 1)) == 0) {
+		const int sh = __builtin_ctz(ts);
+		const uint32_t lt = q >> (2 * sh), in = q & ((1u << (2 * sh)) - 1u);
+		if (lt >= (uint32_t)P.num_shard_tiles) return false;
+		// (a tile holds a multiple of 64 pixels, a packet an aligned power of two of them): the tile's position is computed for the first lane's
+		const uint32_t lt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lt);
+		const uint32_t t0 = lt0 * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
+		const int tx = (int)(t0 % (uint32_t)P.tiles_x), ty = (int)(t0 / (uint32_t)P.tiles_x);
+		if (lt != lt0) return false;   // cannot happen for a live lane
+		const uint32_t blk = in >> 6;
+		int mx, my;
+		morton6(in & 63u, mx, my);
+		x = (tx << sh) + (int)(blk & ((1u << (sh - 3)) - 1u)) * 8 + mx;
+		y = (ty << sh) + (int)(blk >> (sh - 3)) * 8 + my;
+		return x < P.W && y < P.H;
+	}
 	uint32_t per_tile = (uint32_t)(P.tile_size * P.tile_size);
 	uint32_t lt = q / per_tile, in = q - lt * per_tile;
 	if (lt >= (uint32_t)P.num_shard_tiles) return false;
@@ -2149,8 +2198,9 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	S.geometries = a_geoms;
 	__shared__ WaveStack lds_stack[HXR_BLOCK / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	__shared__ uint32_t lds_pend[(F & HXR_F_STACK1) != 0 ? (HXR_BLOCK / 64) * HXR_PEND_DWORDS * 64 : 1];
-	const Stacks stacks{&lds_stack[wave], LaneStack{nullptr, 0, nullptr}, lds_pend + ((F & HXR_F_STACK1) != 0 ? wave * HXR_PEND_DWORDS * 64 : 0)};
+	constexpr int pend_slots = (F & HXR_F_STACK1) != 0 ? 1 : ((F & HXR_F_LDSSTACK) != 0 ? HXR_LDS_RAY_SLOTS : 0);   // ray stack entries per lane kept in LDS
+	__shared__ uint32_t lds_pend[pend_slots > 0 ? (HXR_BLOCK / 64) * pend_slots * HXR_PEND_DWORDS * 64 : 1];
+	const Stacks stacks{&lds_stack[wave], LaneStack{nullptr, 0, nullptr}, lds_pend + wave * pend_slots * HXR_PEND_DWORDS * 64};
 	Tally<COUNT> tl;
 	tl.clear();
 #ifdef HXR_PHASE_TIMERS

@@ -62,9 +62,12 @@
 #ifndef HXR_SPHERE_GI_WAVES
 #define HXR_SPHERE_GI_WAVES 3   // smallpt 16 paths: 37.2 ms at 2, 31.4 at 3, 32.3 at 4 (round 1, before the turns: 2 was 21 % ahead of 3)
 #endif
+#ifndef HXR_HEIGHTFIELD_F
+#define HXR_HEIGHTFIELD_F (HXR_F_HEIGHTFIELD | HXR_F_REFRACT | HXR_F_LDSSTACK)   // the first entries of the per-lane ray stack in LDS (round 3)
+#endif
 #define HXR_VARIANTS_HEIGHTFIELD(X)                  \
-	X(false, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), HXR_HEIGHTFIELD_WAVES) \
-	X(true, (HXR_F_HEIGHTFIELD | HXR_F_REFRACT), HXR_HEIGHTFIELD_WAVES)
+	X(false, HXR_HEIGHTFIELD_F, HXR_HEIGHTFIELD_WAVES) \
+	X(true, HXR_HEIGHTFIELD_F, HXR_HEIGHTFIELD_WAVES)
 
 #define HXR_INSTANTIATE(C, F, W)                                                    \
 	template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
