@@ -572,7 +572,8 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		// (9.13 vs 8.91 ms; 9.02 ms with the slot in registers): the stack entries are touched once per reflected ray, what costs is the
 		// extra live state around the traversal.  Off by default; kept for the measurement.
 		const bool one_pending = s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr;
-		switch (pick_variant(s)) {
+		const int variant = pick_variant(s);
+		switch (variant) {
 			case V_MESH:
 				if (defer) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_DEFER, HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
 				else if (one_pending) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_STACK1, HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);

@@ -22,6 +22,7 @@
 #define HXR_INF 1e99                  // src/constants.h:29
 #define HXR_PI 3.141592653589793238   // src/constants.h:28
 #define HXR_RF_GI_DIFFUSE 2u          // src/vector.h:176
+#define HXR_ACCUM_SCALE 4294967296.0f   // 2^32: one unit of the fixed-point colour sums = 2.3e-10, range +-2.1e9
 #define HXR_RAY_STACK 12              // pending secondary rays per lane (checked against the scene at create time)
 #define HXR_SHADER_STACK 8            // pending (shader, weight) pairs while a hit is being shaded
 #define HXR_DEV __device__ __forceinline__
@@ -1564,6 +1565,10 @@ enum { Q_NONE = 0, Q_CLOSEST = 1, Q_SHADOW = 2 };
 	for (bool wf_done_ = false; !wf_done_;)                                            \
 		for (const int uni = gather_records ? (var) : __builtin_amdgcn_readfirstlane(var); !wf_done_ && (var) == uni; wf_done_ = true)
 
+// How the turn body (hxr_turn_body.inc) is compiled into a variant: see that file
+template <unsigned F>
+constexpr bool turn_through_lambda = (F & HXR_F_GI) != 0 || (F & HXR_F_MESH) == 0;
+
 template <bool COUNT, unsigned F>
 HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& rc, const Stacks& st, Tally<COUNT>& tl, const DeferCtx& dq)
 {
@@ -1677,347 +1682,18 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 	bool in_lights = false;
 
 	bool shadow_turn = false;   // wave-uniform (path tracing only, see below)
-	while (want != Q_NONE) {
-		// Turns (path tracing).  Lanes drift out of step -- one skips a light sample, another ends a path -- and from then on half the wave wants a
-		// closest hit while the other half wants a shadow answer: the traversal serves both at once, but everything AFTER it (step 3 and
-		// the shading below) then runs twice per loop turn, each time for half the lanes.  So when both kinds are asked for, the wave
-		// alternates: a turn serves ONE kind, lanes of the other kind sit it out (no instruction is issued for them that would not be
-		// issued anyway) and are in step from the next turn on.  The work of a lane and its order are unchanged: same frame, same counters.
-		// smallpt 48.2 -> 39.0 ms, cornell box 63.5 -> 57.8 ms (VALU lane utilisation of smallpt was 42 %).  The Whitted integrator loses by it
-		// (meshes 9.33 -> 10.0 ms, kdtree_test 11.8 -> 13.5 ms: a lane there asks for a run of shadow rays, one per light sample, and lanes
-		// that want the next closest hit would wait through it), so it keeps serving whatever is asked.
-		if constexpr (gi) {
-			const bool any_closest = hxr_ballot(want == Q_CLOSEST) != 0, any_shadow = hxr_ballot(want == Q_SHADOW) != 0;
-			const int serve = (any_closest && any_shadow) ? (shadow_turn ? Q_SHADOW : Q_CLOSEST) : (any_closest ? Q_CLOSEST : Q_SHADOW);
-			shadow_turn = serve == Q_CLOSEST;   // the other kind next time
-#ifdef HXR_TURN_STATS   // developer aid: how full are the turns?  dev_stats[0] turns, [1] lanes still tracing, [2] lanes served, [3] closest turns, [4] lanes served in closest turns
-			{
-				const unsigned long long alive = hxr_ballot(true), served = hxr_ballot(want == serve);
-				if (S.dev_stats && (int)(threadIdx.x & 63) == (int)__builtin_ctzll(alive)) {
-					atomicAdd(S.dev_stats + 0, 1ull);
-					atomicAdd(S.dev_stats + 1, (unsigned long long)__popcll(alive));
-					atomicAdd(S.dev_stats + 2, (unsigned long long)__popcll(served));
-					if (serve == Q_CLOSEST) { atomicAdd(S.dev_stats + 3, 1ull); atomicAdd(S.dev_stats + 4, (unsigned long long)__popcll(served)); }
-				}
-			}
-#endif
-			if (want != serve) continue;
-		}
-		// ---- 1. what does this lane ask the scene?
-		d3 qo = cur.o, qd = cur.d;
-		double qlimit = HXR_INF;
-		bool qany = false;
-		if (want == Q_CLOSEST) {
-			if (gi && intensity(cur.weight) < 0.001f) { want = Q_NONE; continue; }              // pathtrace early exit, src/main.cpp:118
-			tl.add(HC_RAYCASTS);
-			if (cur.depth > S.settings.max_trace_depth) {                                       // src/main.cpp:65: black
-				if (!gi && top > 0) pop_ray();
-				else want = Q_NONE;
-				continue;
-			}
-		} else {
-			tl.add(HC_SHADOW);
-			d3 A = gi ? hp.ip + hp.norm * 1e-6 : lp;                                             // path: surface -> light (src/main.cpp:155)
-			d3 B = gi ? lp : hp.ip + hp.norm * 1e-6;                                             // direct lighting: light -> surface (src/shading.cpp:81,126)
-			qo = A;
-			qlimit = dist3(A, B);
-			qd = unit(B - A);
-			qany = true;
-		}
-
-		// ---- 2. the one traversal site
-		GeomHit bg;
-		double bw;
-		tl.template lap<PH_SHADE>();
-		int node = scene_query<COUNT, F>(S, qo, qd, qlimit, qany, bg, bw, st, tl);
-		tl.template lap<PH_QUERY>();
-
-		// ---- 3. consume the answer
-		bool run_shaders = false;   // Whitted: continue with the shader work list of the current hit
-		bool path_vertex = false;   // path tracing: continue at the current vertex
-		if (want == Q_SHADOW) {
-			bool blocked = node >= 0;
-			for (int k = 0; k < S.num_lights && !blocked; k++) {
-				double dd = qlimit;
-				if (light_query<rect>(S.lights[k], qo, qd, dd)) blocked = true;
-			}
-			if (!blocked) {
-				HXR_WATERFALL(cur_shader, u_sh) HXR_WATERFALL(li, u_li) {
-					const hxr_shader& sh = S.shaders[u_sh];
-					const hxr_light& L = S.lights[u_li];
-					if (!gi) {   // the light sample reaches the surface: Lambert / Phong term (src/shading.cpp:84-85,129-141)
-						d3 to_ip = hp.ip - lp;
-						double d2 = len2(to_ip);
-						float lt = (float)fmax(0.0, dot(hp.norm, unit(-to_ip)));
-						if (sh.type == HXR_SHADER_PHONG) {
-							d3 from_light = unit(hp.ip - lp);
-							d3 refl = reflect3(from_light, faceforward(from_light, hp.norm));
-							float cg = (float)dot(-cur.d, refl);
-							if (cg > 0) sum = sum + (ldf(sh.specular) * lc) * powf(cg, sh.exponent);
-						}
-						sum = sum + (base * lc) * (float)(lt * L.power / d2);
-					} else {     // explicit light sampling of the path tracer (src/main.cpp:157-168)
-						d3 w_out = unit(lp - hp.ip);
-						f3 ev = mkf(1, 0, 0);   // BRDF::eval: Lambert src/shading.cpp:93-97, Reflection :189-194, Refraction :234-239, default :32-35
-						if (sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG) {
-							// the reference samples the texture once in spawnRay and again here; the value is the same, so the kernel kept it
-							// (`base`) and only the work counter notes the second bilinear lookup
-							if (COUNT && sh.texture >= 0 && S.textures[sh.texture].type == HXR_TEX_BITMAP) tl.add(HC_TEX);
-							ev = (base * (float)(1 / HXR_PI)) * (float)fabs(dot(w_out, hp.norm));
-						}
-						else if (sh.type == HXR_SHADER_REFLECTION)
-							ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.999999999 ? ldf(sh.color) : mkf(0, 0, 0);
-						else if (sh.type == HXR_SHADER_REFRACTION)
-							ev = dot(reflect3(cur.d, faceforward(cur.d, hp.norm)), w_out) > 0.99999999 ? ldf(sh.color) : mkf(0, 0, 0);
-						f3 from_light = ((ldf(L.color) * L.power) * L.scale_factor) * ev;
-						if (intensity(from_light) > 0) {
-							float p_choose = 1.0f / (float)S.num_lights;
-							float p_hit = (float)(1.0f / light_solid_angle<rect>(L, hp.ip));
-							acc = acc + fdiv(from_light * cur.weight, p_choose * p_hit);
-						}
-					}
-				}
-			}
-			if (!gi) { ls++; run_shaders = true; }
-			else { in_lights = false; path_vertex = true; }
-		} else {   // Q_CLOSEST: the rest of TraceContext::raycast (src/main.cpp:76-103)
-			bool lit = false;
-			f3 lcol = mkf(0, 0, 0);
-			for (int k = 0; k < S.num_lights; k++) {
-				const hxr_light& L = S.lights[k];
-				int side = light_query<rect>(L, qo, qd, bw);
-				if (side == -1) { lit = true; lcol = mkf(0, 0, 0); }
-				else if (side == 1) { lit = true; lcol = (ldf(L.color) * L.power) * L.scale_factor; }
-			}
-			if (lit || bw >= HXR_INF) {   // the ray ends here
-				f3 early;
-				if (lit) early = (cur.flags & HXR_RF_GI_DIFFUSE) ? mkf(0, 0, 0) : lcol;
-				else early = S.environment.present ? environment_lookup<COUNT>(S, qd, tl) : ldf(S.settings.background);
-				acc = acc + early * cur.weight;
-				if (!gi && top > 0) pop_ray();
-				else want = Q_NONE;
-			} else {
-				HXR_WATERFALL(node, u_node) {
-					Surface sf;
-					surface_of<COUNT, F>(S, u_node, qo, qd, bg, bw, sf, tl);
-					int bump = S.nodes[u_node].bump;
-					if (bump >= 0) texture_bump<COUNT, F>(S, bump, sf, tl);
-					hp.ip = sf.ip;
-					hp.norm = sf.norm;
-					hp.u = sf.u;
-					hp.v = sf.v;
-					cur_shader = S.nodes[u_node].shader;
-				}
-				if (!gi) {
-					stop = 0;
-					sh_stack[stop] = cur_shader;
-					w_stack[stop++] = cur.weight;
-					in_lights = false;
-					run_shaders = true;
-				} else {
-					in_lights = true;   // "before the light sample"
-					path_vertex = true;
-				}
-			}
-		}
-
-		tl.template lap<PH_ENDS>();
-		if (gi && path_vertex) {
-			// ---- path tracing: one vertex = [light sample] then spawn (src/main.cpp:122-168)
-			Surface sfl;   // texture_sample() reads u, v, norm
-			sfl.ip = hp.ip; sfl.norm = hp.norm; sfl.u = hp.u; sfl.v = hp.v;
-			bool ask_shadow = false, dead = false;
-			RayItem nx = cur;
-			HXR_WATERFALL(cur_shader, u_sh) {
-				const hxr_shader& sh = S.shaders[u_sh];
-				const bool diffuse = sh.type == HXR_SHADER_LAMBERT || sh.type == HXR_SHADER_PHONG;
-				// BRDF::spawnRay must succeed first (pdf <= 0 ends the path before any light sampling, src/main.cpp:129-130)
-				d3 refr_dir = mk3(0, 0, 0);
-				bool spawn_ok = diffuse || sh.type == HXR_SHADER_REFLECTION;
-				if (sh.type == HXR_SHADER_REFRACTION)
-					spawn_ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), refr_dir) : refract_dir(cur.d, -hp.norm, (float)sh.ior, refr_dir);
-				if (!spawn_ok) dead = true;
-				else {
-					if (in_lights) {   // first visit of this vertex: try the explicit light sample
-						in_lights = false;
-						if (diffuse) base = sh.texture >= 0 ? texture_sample<COUNT, F>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
-						if (S.num_lights > 0) {
-							HxrRand128 pick = hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_PICK);
-							li = (int)hxr_below(pick.w0, (uint32_t)S.num_lights);
-							HXR_WATERFALL(li, u_li) {
-								const hxr_light& L = S.lights[u_li];
-								if (light_solid_angle<rect>(L, hp.ip) > 0) {
-									int idx = (int)hxr_below(pick.w2, (uint32_t)light_num_samples<rect>(L));
-									double j1, j2;
-									hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_LIGHT_JITTER), j1, j2);
-									f3 unused;
-									light_sample<rect>(L, idx, hp.ip, j1, j2, lp, unused);
-									ask_shadow = true;
-								}
-							}
-						}
-					}
-					if (!ask_shadow) {
-						// spawn the next ray: Lambert src/shading.cpp:99-109, Reflection :196-205, Refraction :241-263
-						nx.depth = cur.depth + 1;
-						nx.key = hxr_child_key(cur.key, u_sh, 0);
-						f3 bc;
-						float pdf;
-						if (diffuse) {
-							d3 N = faceforward(cur.d, hp.norm);
-							nx.o = hp.ip + N * 1e-6;
-							double u, v;
-							hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_HEMISPHERE), u, v);
-							nx.d = hemisphere(u, v, N);
-							nx.flags |= HXR_RF_GI_DIFFUSE;
-							bc = (base * (float)(1 / HXR_PI)) * (float)dot(nx.d, N);
-							pdf = (float)(1 / (2 * HXR_PI));
-						} else if (sh.type == HXR_SHADER_REFLECTION) {
-							d3 N = faceforward(cur.d, hp.norm);
-							nx.o = hp.ip + N * 1e-6;
-							nx.d = reflect3(cur.d, N);
-							nx.flags &= ~HXR_RF_GI_DIFFUSE;
-							bc = ldf(sh.color) * 1e+6f;
-							pdf = 1e+6f;
-						} else {
-							nx.o = hp.ip - faceforward(cur.d, hp.norm) * 0.000001;
-							nx.d = refr_dir;
-							nx.flags &= ~HXR_RF_GI_DIFFUSE;
-							bc = ldf(sh.color) * 1e+6f;
-							pdf = 1e+6f;
-						}
-						nx.weight = fdiv(cur.weight * bc, pdf);
-					}
-				}
-			}
-			if (dead) want = Q_NONE;
-			else if (ask_shadow) want = Q_SHADOW;
-			else { cur = nx; want = Q_CLOSEST; }
-		}
-
-		if (!gi && run_shaders) {
-			// ---- Whitted: run the shader work list until a light sample needs a shadow ray or the list is empty
-			Surface sfl;
-			sfl.ip = hp.ip; sfl.norm = hp.norm; sfl.u = hp.u; sfl.v = hp.v;
-			bool settled = false;   // this lane knows what it wants next
-			while (!settled) {
-				if (in_lights) {   // Lambert / Phong light loops (src/shading.cpp:74-88,119-142)
-					bool asked = false;
-					while (li < S.num_lights && !asked) {
-						HXR_WATERFALL(li, u_li) {
-							const hxr_light& L = S.lights[u_li];
-							int n = light_num_samples<rect>(L);
-							if (ls < n) {
-								double j1 = 0, j2 = 0;
-								if (rect && L.type == HXR_LIGHT_RECT)
-									hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, cur.key, HXR_DIM_DIRECT_LIGHT + (uint32_t)u_li * 4096u + (uint32_t)ls), j1, j2);
-								light_sample<rect>(L, ls, hp.ip, j1, j2, lp, lc);
-								if (is_zero(lc)) ls++;
-								else asked = true;
-							} else {
-								direct = direct + fdiv(sum, (float)n);
-								sum = mkf(0, 0, 0);
-								li++;
-								ls = 0;
-							}
-						}
-					}
-					if (asked) { want = Q_SHADOW; settled = true; }
-					else {
-						acc = acc + (direct + base * ldf(S.settings.ambient)) * cur_w;
-						in_lights = false;
-					}
-				} else if (stop == 0) {   // this hit is done: next pending ray
-					if (top > 0) { pop_ray(); want = Q_CLOSEST; }
-					else want = Q_NONE;
-					settled = true;
-				} else {
-					int si = sh_stack[--stop];
-					f3 w = w_stack[stop];
-					HXR_WATERFALL(si, u_si) {
-						const hxr_shader& sh = S.shaders[u_si];
-						switch (sh.type) {
-							case HXR_SHADER_LAMBERT:
-							case HXR_SHADER_PHONG:
-								cur_shader = u_si;
-								cur_w = w;
-								base = sh.texture >= 0 ? texture_sample<COUNT, F>(S, sh.texture, cur.d, sfl, tl) : ldf(sh.color);
-								direct = mkf(0, 0, 0);
-								sum = mkf(0, 0, 0);
-								li = 0;
-								ls = 0;
-								in_lights = true;
-								break;
-							case HXR_SHADER_CONST: acc = acc + ldf(sh.color) * w; break;
-							case HXR_SHADER_REFLECTION: {   // src/shading.cpp:159-187 (mirror branch; glossy: generator entry below)
-								d3 n = faceforward(cur.d, hp.norm);
-								if constexpr (defer) {
-									emit_ray(dq, hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0), rc.pixel, rc.sample);
-								} else if constexpr (one) {
-									if (top == 0) {
-										pend_store(RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)});
-										top = 1;
-									}
-								} else if (lds_slots > 0 && top < lds_slots) {
-									pend_store(RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)}, top);
-									top++;
-								} else if (top < HXR_RAY_STACK) {
-									StackItem<glossy>& e = stack[top++ - lds_slots];
-									e.r = RayItem{hp.ip + n * 1e-6, reflect3(cur.d, n), ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
-									if constexpr (glossy) {
-										e.left = 0;
-										if (sh.glossiness < 1.0f) {   // numSamples perturbed mirrors, averaged (src/shading.cpp:165-184)
-											e.r.d = cur.d;
-											e.r.weight = fdiv(ldf(sh.color) * w, (float)sh.num_samples);
-											e.r.key = cur.key;
-											e.n = n;
-											e.left = sh.num_samples;
-											e.shader = u_si;
-										}
-									}
-								}
-								break;
-							}
-							case HXR_SHADER_REFRACTION: {   // src/shading.cpp:216-232
-								if constexpr ((F & HXR_F_REFRACT) != 0) {
-									d3 out;
-									bool ok = dot(cur.d, hp.norm) < 0 ? refract_dir(cur.d, hp.norm, (float)(1 / sh.ior), out) : refract_dir(cur.d, -hp.norm, (float)sh.ior, out);
-									if constexpr (defer) {
-										if (ok) emit_ray(dq, hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0), rc.pixel, rc.sample);
-									} else if constexpr (one) {
-										if (ok && top == 0) {
-											pend_store(RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)});
-											top = 1;
-										}
-									} else if (ok && lds_slots > 0 && top < lds_slots) {
-										pend_store(RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)}, top);
-										top++;
-									} else if (ok && top < HXR_RAY_STACK) {
-										StackItem<glossy>& e = stack[top++ - lds_slots];
-										e.r = RayItem{hp.ip - faceforward(cur.d, hp.norm) * 0.000001, out, ldf(sh.color) * w, cur.depth + 1, cur.flags, hxr_child_key(cur.key, u_si, 0)};
-										if constexpr (glossy) e.left = 0;
-									}
-								}
-								break;
-							}
-							case HXR_SHADER_LAYERED: {      // src/shading.cpp:315-324: col = col*(1-blend) + layer*blend, first to last
-								f3 rem = mkf(1, 1, 1);      // product of (1 - blend) over the layers ABOVE the current one
-								for (int i = sh.num_layers - 1; i >= 0; i--) {
-									const hxr_layer& Ly = S.layers[sh.first_layer + i];
-									f3 blend = Ly.texture >= 0 ? texture_sample<COUNT, F>(S, Ly.texture, cur.d, sfl, tl) : ldf(Ly.blend);
-									if (stop < HXR_SHADER_STACK) {
-										sh_stack[stop] = Ly.shader;
-										w_stack[stop++] = (w * blend) * rem;
-									}
-									rem = rem * (mkf(1, 1, 1) - blend);
-								}
-								break;
-							}
-							default: break;
-						}
-					}
-				}
-			}
+	if constexpr (turn_through_lambda<F>) {
+		auto turn = [&]() __attribute__((always_inline)) {
+#define HXR_TURN_NEXT return
+#include "hxr_turn_body.inc"
+#undef HXR_TURN_NEXT
+		};
+		while (want != Q_NONE) turn();
+	} else {
+		while (want != Q_NONE) {
+#define HXR_TURN_NEXT continue
+#include "hxr_turn_body.inc"
+#undef HXR_TURN_NEXT
 		}
 	}
 	return acc;
@@ -2094,6 +1770,8 @@ HXR_DEV void morton6(uint32_t m, int& x, int& y)
 	y = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
 }
 
+HXR_DEV bool shard_pixel_general(const HxrLaunch& P, uint32_t q, int& x, int& y);
+
 HXR_DEV bool shard_pixel(const HxrLaunch& P, uint32_t q, int& x, int& y)
 {
 	const int ts = P.tile_size;
@@ -2116,6 +1794,12 @@ HXR_DEV bool shard_pixel(const HxrLaunch& P, uint32_t q, int& x, int& y)
 		y = (ty << sh) + (int)(blk >> (sh - 3)) * 8 + my;
 		return x < P.W && y < P.H;
 	}
+	return shard_pixel_general(P, q, x, y);
+}
+
+// ... for any tile size, every lane for itself
+HXR_DEV bool shard_pixel_general(const HxrLaunch& P, uint32_t q, int& x, int& y)
+{
 	uint32_t per_tile = (uint32_t)(P.tile_size * P.tile_size);
 	uint32_t lt = q / per_tile, in = q - lt * per_tile;
 	if (lt >= (uint32_t)P.num_shard_tiles) return false;
@@ -2481,7 +2165,6 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 // and every lane runs raytrace() on its ray to the end (further bounces wait on the per-lane stack as before).  What the ray
 // contributes to its pixel is `weight x colour` by linearity; it is added into HxrLaunch::q_accum as 64-bit fixed point, so the
 // sum does not depend on the order in which waves finish.  F: the in-place variant of the integrator (no HXR_F_DEFER).
-#define HXR_ACCUM_SCALE 4294967296.0f   // 2^32: one unit = 2.3e-10, range +-2.1e9
 #define HXR_LANE_BLOCK 128   // threads per block of the per-lane-walk continuation kernels: two waves share 2 x entries x 256 B of LDS
 template <bool COUNT, unsigned F, int W>
 __global__ __launch_bounds__(((F & HXR_F_LANEWALK) != 0 ? HXR_LANE_BLOCK : HXR_BLOCK), W) void hxr_continue_kernel(
