@@ -645,10 +645,12 @@ void halo_pixels(const Plan& p, std::vector<int32_t>& out)
 	out.clear();
 	if (p.count <= 1) return;
 	std::vector<uint8_t> mark((size_t)p.W * p.H, 0);
-	auto own = [&](int x, int y) { return ((y / p.tile) * p.tiles_x + x / p.tile) % p.count == p.rank; };
+	auto own = [&](int x, int y) { return hxr_tile_number(x / p.tile, y / p.tile, p.tiles_x, p.count) % p.count == p.rank; };
 	for (int i = 0; i < p.ntiles; i++) {
 		int t = i * p.count + p.rank;
-		int x0 = (t % p.tiles_x) * p.tile, y0 = (t / p.tiles_x) * p.tile;
+		int tx_, ty_;
+		hxr_tile_position(t, p.tiles_x, p.count, &tx_, &ty_);
+		int x0 = tx_ * p.tile, y0 = ty_ * p.tile;
 		int x1 = std::min(x0 + p.tile, p.W), y1 = std::min(y0 + p.tile, p.H);
 		for (int y = y0 - 1; y <= y1; y++)
 			for (int x = x0 - 1; x <= x1; x++) {
@@ -1359,9 +1361,10 @@ int hxr_shard_tile_rect(const hxr_scene* s, const hxr_frame_params* fp, int i, i
 	int rc = resolve(s, fp, p);
 	if (rc) return rc;
 	if (i < 0 || i >= p.ntiles) { set_err("tile index outside the shard"); return HXR_E_INVALID; }
-	int t = i * p.count + p.rank;
-	*x0 = (t % p.tiles_x) * p.tile;
-	*y0 = (t / p.tiles_x) * p.tile;
+	int t = i * p.count + p.rank, tx_, ty_;
+	hxr_tile_position(t, p.tiles_x, p.count, &tx_, &ty_);
+	*x0 = tx_ * p.tile;
+	*y0 = ty_ * p.tile;
 	*x1 = std::min(*x0 + p.tile, p.W);
 	*y1 = std::min(*y0 + p.tile, p.H);
 	return 0;
@@ -1442,9 +1445,10 @@ int hxr_render(hxr_scene* s, const hxr_frame_params* fp, float* vfb, size_t row_
 	HIP_TRY(hipEventRecord(s->ev_done, s->main_stream));
 	std::vector<char> reported((size_t)p.ntiles, 0);
 	auto tile_rect = [&](int i, int& x0, int& y0, int& x1, int& y1) {
-		int t = i * p.count + p.rank;
-		x0 = (t % p.tiles_x) * p.tile;
-		y0 = (t / p.tiles_x) * p.tile;
+		int t = i * p.count + p.rank, tx_, ty_;
+		hxr_tile_position(t, p.tiles_x, p.count, &tx_, &ty_);
+		x0 = tx_ * p.tile;
+		y0 = ty_ * p.tile;
 		x1 = std::min(x0 + p.tile, p.W);
 		y1 = std::min(y0 + p.tile, p.H);
 	};
@@ -2030,7 +2034,9 @@ int hxr_group_render(hxr_group* g, const hxr_frame_params* fp, float* vfb, size_
 	HIP_TRY(hipMemcpy2D(vfb, row_stride_bytes, g->d_frame, dstride, dstride, p0.H, hipMemcpyDeviceToHost));
 	if (cb)
 		for (int t = 0; t < p0.tiles_x * p0.tiles_y; t++) {
-			int x0 = (t % p0.tiles_x) * p0.tile, y0 = (t / p0.tiles_x) * p0.tile;
+			int tx_, ty_;
+			hxr_tile_position(t, p0.tiles_x, n, &tx_, &ty_);
+			int x0 = tx_ * p0.tile, y0 = ty_ * p0.tile;
 			cb(user, x0, y0, std::min(x0 + p0.tile, p0.W), std::min(y0 + p0.tile, p0.H));
 		}
 	return 0;

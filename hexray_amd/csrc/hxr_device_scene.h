@@ -23,6 +23,28 @@
 
 #define HXR_KD_LEAF 3
 
+// Tile dealing (include/hexray_hip.h, "sharding").  Tiles are numbered row-major, number t belongs to shard t % N and is that shard's
+// local tile t / N.  With N > 1 the numbers of tile row ty are rotated by HXR_TILE_SKEW * ty columns (number ty * tiles_x + v sits at
+// column (v - HXR_TILE_SKEW * ty) mod tiles_x): 1920 / 8 = 240 tile columns are a multiple of 8, so without the rotation a shard would
+// own the same columns in every row and a vertical image feature -- the crease of the heart in data/meshes.hexray -- would land on
+// the same two or three GPUs all the way down (measured on the 8-way split of the headline frame: slowest rank 1.62 ms against a mean of 1.44).
+#define HXR_TILE_SKEW 3
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define HXR_HD __host__ __device__
+#else
+#define HXR_HD
+#endif
+HXR_HD inline void hxr_tile_position(int t, int tiles_x, int shard_count, int* tx, int* ty)
+{
+	*ty = t / tiles_x;
+	const int v = t - *ty * tiles_x;
+	*tx = shard_count > 1 ? (v + tiles_x - (HXR_TILE_SKEW * *ty) % tiles_x) % tiles_x : v;
+}
+HXR_HD inline int hxr_tile_number(int tx, int ty, int tiles_x, int shard_count)
+{
+	return ty * tiles_x + (shard_count > 1 ? (tx + HXR_TILE_SKEW * ty) % tiles_x : tx);
+}
+
 struct HxrKdSlim {         // 16 B
 	double split;          // binary: splitPos
 	int32_t first;         // binary: index of the left child (right = first + 1), local to the mesh;

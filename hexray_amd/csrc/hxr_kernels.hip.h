@@ -1785,7 +1785,8 @@ HXR_DEV bool shard_pixel(const HxrLaunch& P, uint32_t q, int& x, int& y)
 		// (a tile holds a multiple of 64 pixels, a packet an aligned power of two of them): the tile's position is computed for the first lane's
 		const uint32_t lt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lt);
 		const uint32_t t0 = lt0 * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
-		const int tx = (int)(t0 % (uint32_t)P.tiles_x), ty = (int)(t0 / (uint32_t)P.tiles_x);
+		int tx, ty;
+		hxr_tile_position((int)t0, P.tiles_x, P.shard_count, &tx, &ty);
 		if (lt != lt0) return false;   // cannot happen for a live lane
 		const uint32_t blk = in >> 6;
 		int mx, my;
@@ -1804,7 +1805,8 @@ HXR_DEV bool shard_pixel_general(const HxrLaunch& P, uint32_t q, int& x, int& y)
 	uint32_t lt = q / per_tile, in = q - lt * per_tile;
 	if (lt >= (uint32_t)P.num_shard_tiles) return false;
 	uint32_t t = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;   // row-major tile number
-	int tx = (int)(t % (uint32_t)P.tiles_x), ty = (int)(t / (uint32_t)P.tiles_x);
+	int tx, ty;
+	hxr_tile_position((int)t, P.tiles_x, P.shard_count, &tx, &ty);
 	int bpr = P.tile_size / 8;
 	uint32_t blk = in >> 6;
 	int mx, my;
@@ -2471,7 +2473,9 @@ __global__ void hxr_assemble_kernel(const float* __restrict__ gathered, size_t p
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		int per_tile = tile_size * tile_size;
 		int t = (int)(i / per_tile), in = (int)(i % per_tile);
-		int x = (t % tiles_x) * tile_size + in % tile_size, y = (t / tiles_x) * tile_size + in / tile_size;
+		int tx, ty;
+		hxr_tile_position(t, tiles_x, shard_count, &tx, &ty);
+		int x = tx * tile_size + in % tile_size, y = ty * tile_size + in / tile_size;
 		if (x >= W || y >= H) continue;
 		int rank = t % shard_count, lt = t / shard_count;
 		const float* src = gathered + (size_t)rank * per_rank_floats + ((size_t)lt * per_tile + in) * 3;

@@ -1,8 +1,10 @@
 """One-process-per-GPU frame sharding.
 
-The frame is cut into square tiles (row-major tile numbers); tile ``t`` belongs to rank ``t % world``
-and is that rank's local tile ``t // world`` -- round-robin, so expensive image regions spread over all
-GPUs (the reference spreads 64x64 buckets over threads with an atomic cursor, src/main.cpp:273-275).
+The frame is cut into square tiles; tile NUMBER ``t`` belongs to rank ``t % world`` and is that rank's local tile
+``t // world`` -- round-robin, so expensive image regions spread over all GPUs (the reference spreads 64x64 buckets
+over threads with an atomic cursor, src/main.cpp:273-275).  Numbers run row-major, each tile row rotated by
+``TILE_SKEW`` more columns than the one above it (``tile_position``), so that a rank does not own the same columns
+in every row.
 Every rank renders its tiles into one tile-major buffer (``LAYOUT_TILES``); the buffers are collected with
 ONE gather (RCCL over xGMI when the tensors live on GPUs; gloo in the CPU tests) and rank 0 scatters them
 into the row-major frame.  There is no other communication: the scene is replicated and the random
@@ -15,6 +17,16 @@ import numpy as np
 
 def tiles_in_frame(width: int, height: int, tile: int):
     return (width - 1) // tile + 1, (height - 1) // tile + 1
+
+
+TILE_SKEW = 3   # HXR_TILE_SKEW (hexray_amd/csrc/hxr_device_scene.h)
+
+
+def tile_position(t: int, tiles_x: int, world: int):
+    """Column and row of tile NUMBER t (hxr_tile_position): with more than one shard the numbers of tile row ty are rotated by TILE_SKEW * ty
+    columns, so that a shard does not own the same columns in every row."""
+    ty, v = divmod(t, tiles_x)
+    return ((v - TILE_SKEW * ty) % tiles_x if world > 1 else v), ty
 
 
 def shard_tile_count(width: int, height: int, tile: int, rank: int, world: int) -> int:
@@ -57,7 +69,8 @@ def assemble_tiles_numpy(gathered: np.ndarray, width: int, height: int, tile: in
     for t in range(tx * ty):
         r, lt = t % world, t // world
         block = g[r, lt * tile * tile * 3:(lt + 1) * tile * tile * 3].reshape(tile, tile, 3)
-        x0, y0 = (t % tx) * tile, (t // tx) * tile
+        cx, cy = tile_position(t, tx, world)
+        x0, y0 = cx * tile, cy * tile
         x1, y1 = min(x0 + tile, width), min(y0 + tile, height)
         frame[y0:y1, x0:x1] = block[:y1 - y0, :x1 - x0]
     return frame

@@ -270,7 +270,9 @@ typedef struct hxr_frame_params {
 	int32_t spp;              /* MONTE_CARLO: rays per pixel; 0 = max(dof ? camera.num_samples : 0, gi ? num_paths : 0) */
 	uint64_t rng_seed;        /* counter-based generator key; 5489 = std::mt19937's default seed, used as OUR default */
 	int32_t tile_size;        /* sharding granule in pixels (square); 0 = 64 like the reference's buckets (src/main.cpp:515) */
-	int32_t shard_rank;       /* this process renders tiles t with t % shard_count == shard_rank (row-major tile order) */
+	int32_t shard_rank;       /* this process renders the tiles whose NUMBER t has t % shard_count == shard_rank.  Numbers run row-major; with
+	                             shard_count > 1 every tile row is rotated by three more columns than the row above it, so that a shard does not own
+	                             the same columns all the way down (hxr_shard_tile_rect gives the rectangles; hxr_assemble_frame undoes it) */
 	int32_t shard_count;      /* 0 or 1 = whole frame */
 	int32_t layout;           /* hxr_output_layout */
 	int32_t collect_counters; /* nonzero: run the instrumented kernel build and fill hxr_get_counters() */

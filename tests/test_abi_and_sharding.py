@@ -49,7 +49,7 @@ def test_error_codes_without_a_gpu_or_scene():
 
 
 def test_shard_bookkeeping_matches_python_mirror():
-    from hexray_amd.distributed import shard_tile_count, tiles_in_frame
+    from hexray_amd.distributed import shard_tile_count, tile_position, tiles_in_frame
     lib = hx.hip_lib()
     for (w, h, tile, world) in ((1920, 1080, 64, 1), (1920, 1080, 32, 8), (640, 480, 64, 3), (100, 60, 16, 4)):
         tx, ty = tiles_in_frame(w, h, tile)
@@ -64,7 +64,10 @@ def test_shard_bookkeeping_matches_python_mirror():
                 assert lib.hxr_shard_tile_rect(None, ctypes.byref(p), i, *r) == 0
                 x0, y0, x1, y1 = (v.value for v in r)
                 t = i * world + rank
-                assert (x0, y0) == ((t % tx) * tile, (t // tx) * tile)
+                cx, cy = tile_position(t, tx, world)
+                assert (x0, y0) == (cx * tile, cy * tile)
+                if world == 1:
+                    assert (cx, cy) == (t % tx, t // tx)          # a single shard walks the frame row by row
                 seen[y0:y1, x0:x1] += 1
         assert seen.min() == 1 and seen.max() == 1
 
