@@ -275,6 +275,8 @@ def hip_lib():
         lib.hxr_scene_tree_stats.argtypes = [c_void_p, c_int, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(c_int)]
         lib.hxr_kd_build_device.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64),
                                             POINTER(c_int), POINTER(c_double)]
+        lib.hxr_sah_build_device.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64),
+                                            POINTER(c_int), POINTER(c_double)]
         lib.hxr_sah_build.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), POINTER(c_int)]
         lib.hxr_scene_update_camera.argtypes = [c_void_p, c_void_p]
         lib.hxr_scene_verify_tables.argtypes = [c_void_p, c_void_p, POINTER(ctypes.c_int64)]
@@ -349,6 +351,24 @@ def kd_build_device(host_scene: "HostScene", mesh: int = 0):
     leaf = np.zeros(max(1, nl.value), dtype=np.int32)
     _check(lib.hxr_kd_build_device(host_scene.desc, mesh, nodes.ctypes.data, nn.value, leaf.ctypes.data, leaf.size, nn, nl, depth, ms), "hxr_kd_build_device")
     return nodes, leaf[:nl.value], depth.value, ms.value
+
+
+def sah_build(host_scene: "HostScene", mesh: int = 0, device: bool = True):
+    """The module's SAH kd-tree of mesh ``mesh``: built by kernels (hxr_sah_build_device) or by the host builder (hxr_sah_build).
+    Returns (nodes [KD_NODE_DTYPE], leaf_indices [int32], max_depth, build_ms or None)."""
+    lib = hip_lib()
+    nn, nl, depth, ms = ctypes.c_int64(), ctypes.c_int64(), c_int(), c_double()
+    if device:
+        _check(lib.hxr_sah_build_device(host_scene.desc, mesh, None, 0, None, 0, nn, nl, depth, ms), "hxr_sah_build_device")
+    else:
+        _check(lib.hxr_sah_build(host_scene.desc, mesh, None, 0, None, 0, nn, nl, depth), "hxr_sah_build")
+    nodes = np.zeros(nn.value, dtype=KD_NODE_DTYPE)
+    leaf = np.zeros(max(1, nl.value), dtype=np.int32)
+    if device:
+        _check(lib.hxr_sah_build_device(host_scene.desc, mesh, nodes.ctypes.data, nn.value, leaf.ctypes.data, leaf.size, nn, nl, depth, ms), "hxr_sah_build_device")
+    else:
+        _check(lib.hxr_sah_build(host_scene.desc, mesh, nodes.ctypes.data, nn.value, leaf.ctypes.data, leaf.size, nn, nl, depth), "hxr_sah_build")
+    return nodes, leaf[:nl.value], depth.value, (ms.value if device else None)
 
 
 class DeviceScene:

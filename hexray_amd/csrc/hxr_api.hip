@@ -1050,18 +1050,32 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 		const int32_t* leaf_idx = d->leaf_indices + m.first_leaf_index;
 		int64_t num_nodes = m.num_kd_nodes, num_leaf_entries = m.num_leaf_indices;
 		hxr_sah::SahTree sah;
+		hxr_kd::DeviceBuiltTree built;
 		if (accel == HXR_ACCEL_SAH && o.has_kd) {   // meshes the caller wants brute-forced (useKDTree off) stay that way
 			hxr_sah::SahParams sp;
 			if (const char* e = getenv("HXR_SAH_TRAVERSAL_COST")) sp.traversal_cost = atof(e);   // developer aids for tuning the cost model
 			if (const char* e = getenv("HXR_SAH_EMPTY_BONUS")) sp.empty_bonus = atof(e);
 			if (const char* e = getenv("HXR_SAH_MIN_LEAF")) sp.min_leaf = atoi(e);
-			hxr_sah::SahBuilder(d->triangles + m.first_triangle, m.num_triangles, d->f64_pool + m.first_vertex * 3, sp).build(m.bbox_min, m.bbox_max, sah);
-			nodes = sah.nodes.data();
-			leaf_idx = sah.leaf_indices.data();
-			num_nodes = (int64_t)sah.nodes.size();
-			num_leaf_entries = (int64_t)sah.leaf_indices.size();
+			if (getenv("HXR_SAH_HOST")) {   // the host builder (hxr_accel.h): what the device build is compared with
+				hxr_sah::SahBuilder(d->triangles + m.first_triangle, m.num_triangles, d->f64_pool + m.first_vertex * 3, sp).build(m.bbox_min, m.bbox_max, sah);
+				nodes = sah.nodes.data();
+				leaf_idx = sah.leaf_indices.data();
+				num_nodes = (int64_t)sah.nodes.size();
+				num_leaf_entries = (int64_t)sah.leaf_indices.size();
+			} else {                        // the same tree built by kernels over the tables uploaded above (hxr_kd_build.hip)
+				char why[256] = "";
+				if (hxr_kd::build_sah_tree(d_tris + m.first_triangle, m.num_triangles, d_f64 + m.first_vertex * 3, m.bbox_min, m.bbox_max, sp.traversal_cost, sp.intersect_cost,
+				                           sp.empty_bonus, sp.max_depth, sp.min_leaf, built, why, sizeof why)) {
+					set_err("SAH build of mesh %lld: %s", (long long)i, why);
+					return fail();
+				}
+				nodes = built.nodes.data();
+				leaf_idx = built.leaf_indices.data();
+				num_nodes = (int64_t)built.nodes.size();
+				num_leaf_entries = (int64_t)built.leaf_indices.size();
+				s->kd_build_ms += built.build_ms;
+			}
 		}
-		hxr_kd::DeviceBuiltTree built;
 		if (accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD && o.has_kd) {   // Mesh::buildKD as kernels, over the tables uploaded above
 			char why[256] = "";
 			if (hxr_kd::build_reference_tree(d_tris + m.first_triangle, m.num_triangles, d_f64 + m.first_vertex * 3, m.bbox_min, m.bbox_max, built, why, sizeof why)) {
@@ -1624,8 +1638,23 @@ int hxr_sah_build(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t
 	return 0;
 }
 
+static int build_tree_on_device(bool sah, const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf,
+                                int64_t* num_nodes, int64_t* num_leaf, int* max_depth, double* build_ms);
+
 int hxr_kd_build_device(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf, int64_t* num_nodes,
                         int64_t* num_leaf, int* max_depth, double* build_ms)
+{
+	return build_tree_on_device(false, d, mesh, nodes, max_nodes, leaf_indices, max_leaf, num_nodes, num_leaf, max_depth, build_ms);
+}
+
+int hxr_sah_build_device(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf, int64_t* num_nodes,
+                         int64_t* num_leaf, int* max_depth, double* build_ms)
+{
+	return build_tree_on_device(true, d, mesh, nodes, max_nodes, leaf_indices, max_leaf, num_nodes, num_leaf, max_depth, build_ms);
+}
+
+static int build_tree_on_device(bool sah, const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf,
+                                int64_t* num_nodes, int64_t* num_leaf, int* max_depth, double* build_ms)
 {
 	if (g_device < 0) { set_err("hxr_init has not been called"); return HXR_E_INVALID; }
 	if (!d || mesh < 0 || mesh >= d->num_meshes) { set_err("no such mesh"); return HXR_E_INVALID; }
@@ -1647,6 +1676,11 @@ int hxr_kd_build_device(const hxr_scene_desc* d, int mesh, hxr_kd_node* nodes, i
 	    hipMemcpy(d_verts, d->f64_pool + m.first_vertex * 3, (size_t)m.num_vertices * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
 		set_err("upload of the mesh failed");
 		rc = HXR_E_HIP;
+	} else if (sah) {
+		const hxr_sah::SahParams sp;
+		if ((rc = hxr_kd::build_sah_tree(d_tris, m.num_triangles, d_verts, m.bbox_min, m.bbox_max, sp.traversal_cost, sp.intersect_cost, sp.empty_bonus, sp.max_depth, sp.min_leaf,
+		                                 t, why, sizeof why)) != 0)
+			set_err("SAH build: %s", why);
 	} else if ((rc = hxr_kd::build_reference_tree(d_tris, m.num_triangles, d_verts, m.bbox_min, m.bbox_max, t, why, sizeof why)) != 0) {
 		set_err("kd build: %s", why);
 	}

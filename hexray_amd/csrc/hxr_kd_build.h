@@ -27,6 +27,12 @@ struct DeviceBuiltTree {
 int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
                          DeviceBuiltTree& out, char* err, size_t err_len);
 
+// The surface-area-heuristic tree of hxr_accel.h (hxr_sah::SahBuilder, the module's own optional acceleration structure) built on the device:
+// the same tree node for node (split planes, leaf contents and their order) in the same numbering -- tests/test_gpu_kd_build.py compares them.
+// The five numbers are hxr_sah::SahParams.
+int build_sah_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
+                   double traversal_cost, double intersect_cost, double empty_bonus, int max_depth, int min_leaf, DeviceBuiltTree& out, char* err, size_t err_len);
+
 // Mesh::prepareTriangles (src/mesh.cpp:370-396) on the GPU: gnormal, AB, AC, ABcrossAC, dNdx, dNdy of `num_triangles` records are
 // (re)computed in place from the vertex and uv numbers they carry.  Asynchronous on the null stream; returns 0 or HXR_E_HIP.
 int prepare_triangles(hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double* d_uvs);

@@ -312,6 +312,8 @@ struct DeviceBuffers {   // ONE allocation, sliced (a hipMalloc / hipFree pair c
 	~DeviceBuffers() { if (block) (void)hipFree(block); }
 };
 
+void renumber(const std::vector<hxr_kd_node>& dev_nodes, const std::vector<int32_t>& dev_leaf, DeviceBuiltTree& out);
+
 #define KD_TRY(expr)                                                                                           \
 	do {                                                                                                       \
 		hipError_t e_ = (expr);                                                                                \
@@ -377,11 +379,320 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 	out.levels = levels;
 	out.max_depth = (int)ctl.max_depth;
 
-	// copy back and renumber in the host builder's order: a node's child pair is appended when the node is split, subtrees left first
+	// copy back and renumber in the host builder's order (renumber())
 	std::vector<hxr_kd_node> dev_nodes(ctl.node_cursor);
 	std::vector<int32_t> dev_leaf(ctl.leaf_cursor);
 	KD_TRY(hipMemcpy(dev_nodes.data(), B.nodes, dev_nodes.size() * sizeof(hxr_kd_node), hipMemcpyDeviceToHost));
 	if (!dev_leaf.empty()) KD_TRY(hipMemcpy(dev_leaf.data(), B.leaf, dev_leaf.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+	renumber(dev_nodes, dev_leaf, out);
+	return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The surface-area-heuristic tree of hxr_accel.h (hxr_sah::SahBuilder) built on the device, node for node the same tree.
+//
+// The host builder sorts a node's events per axis and sweeps them.  What the sweep knows at a candidate position p is three counts --
+//     A = triangles (not lying in a plane of this axis) that start left of p,      B = planar ones at or left of p,
+//     C = non-planar ones that end at or left of p:       left count = A + B,       right count = N - C - B
+// -- and those can be counted for every candidate independently: one lane per candidate (two per triangle and axis), every lane
+// running over the node's triangles, which the workgroup stages through LDS 256 at a time.  N x 6N comparisons per node instead of a
+// sort, but they are spread over the whole GPU in chunks of 256 candidates, whatever the node's size (the root of the teapot: 9120
+// triangles, 214 chunks), and each level is two launches: the costs, then -- one workgroup per node -- the choice (the minimum in
+// the host's order: smallest cost, then lowest axis, then smallest position, which is what its strict `<` over axes 0, 1, 2 and
+// ascending positions keeps), the stable partition and the children.  The cost is formed with the host's expression, operation for
+// operation and without contraction, so that ties and near-ties fall the same way: tests/test_gpu_kd_build.py compares the trees.
+struct SahTask {   // 80 B
+	double lo[3], hi[3];
+	int32_t node, first, count, depth;
+	uint32_t chunk_first, pad_[3];
+};
+struct SahChunk { uint32_t task, axis_sub; };   // axis in bits 30..31, which 256 candidates of that axis below
+struct SahCtl {
+	uint32_t side[2][4];   // per side: {tasks, ints of list space claimed, chunks, unused}
+	uint32_t node_cursor, leaf_cursor, error, max_depth;
+};
+struct SahCaps { uint32_t tasks, list, nodes, leaf, chunks; };
+struct SahCosts { double traversal, intersect, empty_bonus; int32_t max_depth, min_leaf; };
+
+__global__ void sah_bounds_kernel(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, uint32_t n, double* __restrict__ blo, double* __restrict__ bhi)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		for (int c = 0; c < 3; c++) {
+			const double a = verts[(size_t)tris[i].v[0] * 3 + c], b = verts[(size_t)tris[i].v[1] * 3 + c], d = verts[(size_t)tris[i].v[2] * 3 + c];
+			blo[(size_t)i * 3 + c] = fmin(a, fmin(b, d));
+			bhi[(size_t)i * 3 + c] = fmax(a, fmax(b, d));
+		}
+}
+
+__device__ inline double sah_area(const double lo[3], const double hi[3])
+{
+#pragma clang fp contract(off)
+	const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+	return 2 * (dx * dy + dy * dz + dz * dx);
+}
+
+// chunks a task of `count` triangles is cut into: per axis, ceil(2 * count / 256)
+__device__ __host__ inline uint32_t sah_chunks(uint32_t count) { return 3u * ((2u * count + 255u) / 256u); }
+
+#define SAH_BLOCK 256
+__global__ __launch_bounds__(SAH_BLOCK) void sah_cost_kernel(const SahTask* __restrict__ tasks_in, const SahChunk* __restrict__ chunks_in, int side_in,
+                                                             const int32_t* __restrict__ list_in, const double* __restrict__ blo, const double* __restrict__ bhi,
+                                                             double* __restrict__ costs, const SahCtl* __restrict__ ctl, SahCosts K)
+{
+#pragma clang fp contract(off)
+	__shared__ double s_start[SAH_BLOCK], s_end[SAH_BLOCK];
+	const uint32_t n_chunks = ctl->side[side_in][2];
+	const int tid = threadIdx.x;
+	for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+		const SahChunk ch = chunks_in[c];
+		const SahTask T = tasks_in[ch.task];
+		const int a = (int)(ch.axis_sub >> 30);
+		const uint32_t N = (uint32_t)T.count, k = (ch.axis_sub & 0x3fffffffu) * SAH_BLOCK + (uint32_t)tid;
+		const double lo_a = T.lo[a], hi_a = T.hi[a];
+		double p = 0;
+		if (k < 2 * N) {
+			const int tri = list_in[T.first + (k >> 1)];
+			const double s = fmax(blo[(size_t)tri * 3 + a], lo_a), e = fmin(bhi[(size_t)tri * 3 + a], hi_a);
+			p = (k & 1) ? e : s;
+		}
+		uint32_t A = 0, B = 0, C = 0;
+		for (uint32_t t0 = 0; t0 < N; t0 += SAH_BLOCK) {
+			__syncthreads();
+			if (t0 + tid < N) {
+				const int tri = list_in[T.first + t0 + tid];
+				s_start[tid] = fmax(blo[(size_t)tri * 3 + a], lo_a);
+				s_end[tid] = fmin(bhi[(size_t)tri * 3 + a], hi_a);
+			}
+			__syncthreads();
+			const uint32_t m = min((uint32_t)SAH_BLOCK, N - t0);
+			for (uint32_t q = 0; q < m; q++) {
+				const double ss = s_start[q], ee = s_end[q];
+				const bool planar = ss == ee;
+				A += (!planar && ss < p) ? 1u : 0u;
+				B += (planar && ss <= p) ? 1u : 0u;
+				C += (!planar && ee <= p) ? 1u : 0u;
+			}
+		}
+		if (k < 2 * N) {
+			double cost = HUGE_VAL;
+			if (hi_a > lo_a && p > lo_a && p < hi_a) {
+				const int cl = (int)(A + B), cr = (int)(N - C - B);
+				double l_hi[3] = {T.hi[0], T.hi[1], T.hi[2]}, r_lo[3] = {T.lo[0], T.lo[1], T.lo[2]};
+				l_hi[a] = p;
+				r_lo[a] = p;
+				const double parent_area = sah_area(T.lo, T.hi);
+				cost = K.traversal + K.intersect * (sah_area(T.lo, l_hi) * cl + sah_area(r_lo, T.hi) * cr) / parent_area;
+				if (cl == 0 || cr == 0) cost *= K.empty_bonus;
+			}
+			costs[6 * (size_t)T.first + (size_t)a * 2 * N + k] = cost;
+		}
+	}
+}
+
+template <int KD_BLOCK>
+__global__ __launch_bounds__(KD_BLOCK) void sah_split_kernel(const SahTask* __restrict__ tasks_in, int side_in, const int32_t* __restrict__ list_in,
+                                                             const double* __restrict__ blo, const double* __restrict__ bhi, const double* __restrict__ costs,
+                                                             SahTask* __restrict__ tasks_out, SahChunk* __restrict__ chunks_out, int32_t* __restrict__ list_out,
+                                                             hxr_kd_node* __restrict__ nodes, int32_t* __restrict__ leaf_idx, SahCtl* __restrict__ ctl, int side_out,
+                                                             SahCaps caps, SahCosts K)
+{
+	__shared__ uint32_t s_claim[6];               // {list base / leaf first, first child node, task slot, overflow, chunk base of the left child, ... of the right child}
+	__shared__ uint32_t s_left[KD_BLOCK / 64], s_right[KD_BLOCK / 64];
+	__shared__ double s_cost[KD_BLOCK / 64][3], s_pos[KD_BLOCK / 64][3];
+	__shared__ double s_best_pos;
+	__shared__ int s_best_axis;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t n_in = ctl->side[side_in][0];
+	for (uint32_t ti = blockIdx.x; ti < n_in; ti += gridDim.x) {
+		const SahTask T = tasks_in[ti];
+		const uint32_t count = (uint32_t)T.count;
+		__syncthreads();   // the previous task's shared words have been read by everyone
+		if (tid == 0) atomicMax(&ctl->max_depth, (uint32_t)T.depth);
+		bool leaf = T.count <= K.min_leaf || T.depth >= K.max_depth;
+		uint32_t n_left = 0, n_right = 0, base = 0;
+		int axis = -1;
+		double pos = 0;
+		if (!leaf) {
+			// the cheapest candidate in the host's order: per axis the smallest cost and, among equals, the smallest position ...
+			double bc[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, bp[3] = {0, 0, 0};
+			for (int a = 0; a < 3; a++) {
+				const double lo_a = T.lo[a], hi_a = T.hi[a];
+				for (uint32_t k = tid; k < 2 * count; k += KD_BLOCK) {
+					const double c = costs[6 * (size_t)T.first + (size_t)a * 2 * count + k];
+					if (c <= bc[a]) {
+						const int tri = list_in[T.first + (k >> 1)];
+						const double p = (k & 1) ? fmin(bhi[(size_t)tri * 3 + a], hi_a) : fmax(blo[(size_t)tri * 3 + a], lo_a);
+						if (c < bc[a] || p < bp[a]) { bc[a] = c; bp[a] = p; }
+					}
+				}
+				for (int off = 32; off > 0; off >>= 1) {
+					const double oc = __shfl_down(bc[a], off, 64), op = __shfl_down(bp[a], off, 64);
+					if (oc < bc[a] || (oc == bc[a] && op < bp[a])) { bc[a] = oc; bp[a] = op; }
+				}
+				if (lane == 0) { s_cost[wave][a] = bc[a]; s_pos[wave][a] = bp[a]; }
+			}
+			__syncthreads();
+			if (tid == 0) {
+				// ... then the axes in turn, each only if STRICTLY cheaper than what is held (hxr_sah::SahBuilder::split's `c < best_cost`),
+				// starting from the cost of leaving the node a leaf
+#pragma clang fp contract(off)
+				double best = K.intersect * T.count;
+				int best_axis = -1;
+				double best_pos = 0;
+				for (int a = 0; a < 3; a++) {
+					double c = HUGE_VAL, p = 0;
+					for (int w = 0; w < KD_BLOCK / 64; w++)
+						if (s_cost[w][a] < c || (s_cost[w][a] == c && s_pos[w][a] < p)) { c = s_cost[w][a]; p = s_pos[w][a]; }
+					if (c < best) { best = c; best_axis = a; best_pos = p; }
+				}
+				s_best_axis = best_axis;
+				s_best_pos = best_pos;
+				uint32_t lb = 0;
+				bool fits = true;
+				if (best_axis >= 0) {
+					lb = atomicAdd(&ctl->side[side_out][1], 2 * count);
+					fits = lb + 2 * count <= caps.list;
+					if (!fits) atomicOr(&ctl->error, 1u);
+				}
+				s_claim[0] = lb;
+				s_claim[3] = fits ? 0 : 1;
+			}
+			__syncthreads();
+			if (s_claim[3]) continue;
+			axis = s_best_axis;
+			pos = s_best_pos;
+			base = s_claim[0];
+			if (axis < 0) leaf = true;
+		}
+		if (!leaf) {
+			// the two lists (hxr_sah::SahBuilder::split): a triangle lying in the plane goes left; otherwise left if it starts left of the
+			// plane, right if it ends right of it.  Stable, like the host's push_back loop.
+			const double lo_a = T.lo[axis], hi_a = T.hi[axis];
+			for (uint32_t c = 0; c < count; c += KD_BLOCK) {
+				const uint32_t i = c + tid;
+				int tri = 0;
+				bool in_left = false, in_right = false;
+				if (i < count) {
+					tri = list_in[T.first + i];
+					const double s = fmax(blo[(size_t)tri * 3 + axis], lo_a), e = fmin(bhi[(size_t)tri * 3 + axis], hi_a);
+					if (s == e && s == pos) in_left = true;
+					else { in_left = s < pos; in_right = e > pos; }
+				}
+				const unsigned long long bl = __ballot(in_left), br = __ballot(in_right), below = (1ull << lane) - 1;
+				if (lane == 0) { s_left[wave] = (uint32_t)__popcll(bl); s_right[wave] = (uint32_t)__popcll(br); }
+				__syncthreads();
+				uint32_t before_l = 0, before_r = 0, total_l = 0, total_r = 0;
+				for (int w = 0; w < KD_BLOCK / 64; w++) {
+					if (w < wave) { before_l += s_left[w]; before_r += s_right[w]; }
+					total_l += s_left[w];
+					total_r += s_right[w];
+				}
+				if (in_left) list_out[base + n_left + before_l + (uint32_t)__popcll(bl & below)] = tri;
+				if (in_right) list_out[base + count + n_right + before_r + (uint32_t)__popcll(br & below)] = tri;
+				n_left += total_l;
+				n_right += total_r;
+				__syncthreads();
+			}
+			if (n_left == count && n_right == count) leaf = true;   // the split separates nothing: a leaf after all
+		}
+		if (leaf) {
+			if (tid == 0) {
+				const uint32_t first = atomicAdd(&ctl->leaf_cursor, count);
+				const bool fits = first + count <= caps.leaf;
+				if (!fits) atomicOr(&ctl->error, 1u);
+				s_claim[0] = first;
+				s_claim[3] = fits ? 0 : 1;
+				hxr_kd_node& n = nodes[T.node];
+				n.axis = 3;
+				n.first = (int32_t)first;
+				n.count = T.count;
+				n.split = 0;
+			}
+			__syncthreads();
+			if (s_claim[3]) continue;
+			const uint32_t first = s_claim[0];
+			for (uint32_t i = tid; i < count; i += KD_BLOCK) leaf_idx[first + i] = list_in[T.first + i];
+			continue;
+		}
+		// the children: node pair, two tasks, and the chunks of those that will be split further
+		const bool deeper = T.depth + 1 < K.max_depth;
+		const uint32_t ch_l = (deeper && (int)n_left > K.min_leaf) ? sah_chunks(n_left) : 0u, ch_r = (deeper && (int)n_right > K.min_leaf) ? sah_chunks(n_right) : 0u;
+		if (tid == 0) {
+			const uint32_t kids = atomicAdd(&ctl->node_cursor, 2u);
+			const uint32_t slot = atomicAdd(&ctl->side[side_out][0], 2u);
+			const uint32_t cb = atomicAdd(&ctl->side[side_out][2], ch_l + ch_r);
+			const bool fits = kids + 2 <= caps.nodes && slot + 2 <= caps.tasks && cb + ch_l + ch_r <= caps.chunks;
+			if (!fits) atomicOr(&ctl->error, 1u);
+			s_claim[1] = kids;
+			s_claim[2] = slot;
+			s_claim[3] = fits ? 0 : 1;
+			s_claim[4] = cb;
+			s_claim[5] = cb + ch_l;
+			if (fits) {
+				hxr_kd_node& n = nodes[T.node];
+				n.axis = axis;
+				n.first = (int32_t)kids;
+				n.count = 0;
+				n.split = pos;
+				nodes[kids].parent = nodes[kids + 1].parent = T.node;
+				SahTask a, b;
+				for (int c = 0; c < 3; c++) { a.lo[c] = b.lo[c] = T.lo[c]; a.hi[c] = b.hi[c] = T.hi[c]; }
+				a.hi[axis] = pos;
+				b.lo[axis] = pos;
+				a.node = (int32_t)kids;      a.first = (int32_t)base;           a.count = (int32_t)n_left;  a.depth = T.depth + 1;  a.chunk_first = cb;
+				b.node = (int32_t)kids + 1;  b.first = (int32_t)(base + count); b.count = (int32_t)n_right; b.depth = T.depth + 1;  b.chunk_first = cb + ch_l;
+				a.pad_[0] = a.pad_[1] = a.pad_[2] = b.pad_[0] = b.pad_[1] = b.pad_[2] = 0;
+				tasks_out[slot] = a;
+				tasks_out[slot + 1] = b;
+			}
+		}
+		__syncthreads();
+		if (s_claim[3]) continue;
+		const uint32_t slot = s_claim[2];
+		for (int side = 0; side < 2; side++) {
+			const uint32_t nch = side ? ch_r : ch_l, first = s_claim[4 + side], per_axis = nch / 3;
+			for (uint32_t i = tid; i < nch; i += KD_BLOCK) chunks_out[first + i] = SahChunk{slot + (uint32_t)side, ((i / per_axis) << 30) | (i % per_axis)};
+		}
+	}
+}
+
+struct SahBuffers {
+	void* block = nullptr;
+	SahTask* tasks[2] = {nullptr, nullptr};
+	SahChunk* chunks[2] = {nullptr, nullptr};
+	int32_t* lists[2] = {nullptr, nullptr};
+	double* costs = nullptr;
+	double *blo = nullptr, *bhi = nullptr;
+	hxr_kd_node* nodes = nullptr;
+	int32_t* leaf = nullptr;
+	SahCtl* ctl = nullptr;
+	hipError_t allocate(const SahCaps& caps, uint32_t n)
+	{
+		auto round = [](size_t v) { return (v + 255) & ~(size_t)255; };
+		const size_t s_tasks = round((size_t)caps.tasks * sizeof(SahTask)), s_chunks = round((size_t)caps.chunks * sizeof(SahChunk)),
+		             s_list = round((size_t)caps.list * sizeof(int32_t)), s_costs = round((size_t)caps.list * 6 * sizeof(double)), s_b = round((size_t)n * 3 * sizeof(double)),
+		             s_nodes = round((size_t)caps.nodes * sizeof(hxr_kd_node)), s_leaf = round((size_t)caps.leaf * sizeof(int32_t)), s_ctl = round(sizeof(SahCtl));
+		const hipError_t e = hipMalloc(&block, 2 * s_tasks + 2 * s_chunks + 2 * s_list + s_costs + 2 * s_b + s_nodes + s_leaf + s_ctl);
+		if (e != hipSuccess) return e;
+		char* at = (char*)block;
+		costs = (double*)at; at += s_costs;
+		blo = (double*)at; at += s_b;
+		bhi = (double*)at; at += s_b;
+		for (int i = 0; i < 2; i++) { tasks[i] = (SahTask*)at; at += s_tasks; }
+		for (int i = 0; i < 2; i++) { chunks[i] = (SahChunk*)at; at += s_chunks; }
+		for (int i = 0; i < 2; i++) { lists[i] = (int32_t*)at; at += s_list; }
+		nodes = (hxr_kd_node*)at; at += s_nodes;
+		leaf = (int32_t*)at; at += s_leaf;
+		ctl = (SahCtl*)at;
+		return hipSuccess;
+	}
+	~SahBuffers() { if (block) (void)hipFree(block); }
+};
+
+// host order of a device-built tree (shared by the two builders): a node's child pair is appended when the node is split, subtrees left first
+void renumber(const std::vector<hxr_kd_node>& dev_nodes, const std::vector<int32_t>& dev_leaf, DeviceBuiltTree& out)
+{
 	out.nodes.clear();
 	out.leaf_indices.clear();
 	out.nodes.reserve(dev_nodes.size());
@@ -414,6 +725,74 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 		todo.push_back({src.first + 1, first + 1});
 		todo.push_back({src.first, first});   // left subtree first
 	}
+}
+
+int sah_attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const double lo[3], const double hi[3], const SahCaps& caps, const SahCosts& K,
+                DeviceBuiltTree& out, bool* overflow, char* err, size_t err_len)
+{
+	*overflow = false;
+	SahBuffers B;
+	KD_TRY(B.allocate(caps, n));
+	const auto t0 = std::chrono::steady_clock::now();
+	SahTask root;
+	memset(&root, 0, sizeof root);
+	for (int c = 0; c < 3; c++) { root.lo[c] = lo[c]; root.hi[c] = hi[c]; }
+	root.node = 0; root.first = 0; root.count = (int32_t)n; root.depth = 0; root.chunk_first = 0;
+	const bool root_splits = (int)n > K.min_leaf && 0 < K.max_depth;
+	const uint32_t root_chunks = root_splits ? sah_chunks(n) : 0u;
+	if (root_chunks > caps.chunks) { *overflow = true; return 0; }
+	std::vector<SahChunk> rc(root_chunks);
+	for (uint32_t i = 0; i < root_chunks; i++) rc[i] = SahChunk{0u, ((i / (root_chunks / 3)) << 30) | (i % (root_chunks / 3))};
+	hxr_kd_node root_node;
+	memset(&root_node, 0, sizeof root_node);
+	root_node.parent = -1;
+	SahCtl ctl;
+	memset(&ctl, 0, sizeof ctl);
+	ctl.side[0][0] = 1;
+	ctl.side[0][1] = n;
+	ctl.side[0][2] = root_chunks;
+	ctl.node_cursor = 1;
+	KD_TRY(hipMemcpy(B.tasks[0], &root, sizeof root, hipMemcpyHostToDevice));
+	if (root_chunks) KD_TRY(hipMemcpy(B.chunks[0], rc.data(), rc.size() * sizeof(SahChunk), hipMemcpyHostToDevice));
+	KD_TRY(hipMemcpy(B.nodes, &root_node, sizeof root_node, hipMemcpyHostToDevice));
+	KD_TRY(hipMemcpy(B.ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
+	if (n) {
+		const int g = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+		hipLaunchKernelGGL(kd_iota_kernel, dim3(g), dim3(256), 0, nullptr, B.lists[0], n);
+		hipLaunchKernelGGL(sah_bounds_kernel, dim3(g), dim3(256), 0, nullptr, d_tris, d_verts, n, B.blo, B.bhi);
+	}
+	enum { LEVELS_PER_LOOK = 8, GRID = 2048, WIDE_LEVELS = 6 };
+	int side_in = 0, levels = 0;
+	bool done = false;
+	while (!done) {
+		for (int k = 0; k < LEVELS_PER_LOOK; k++) {
+			const int side_out = side_in ^ 1;
+			KD_TRY(hipMemsetAsync(&B.ctl->side[side_out][0], 0, 4 * sizeof(uint32_t), nullptr));
+			hipLaunchKernelGGL(sah_cost_kernel, dim3(GRID), dim3(SAH_BLOCK), 0, nullptr, B.tasks[side_in], B.chunks[side_in], side_in, B.lists[side_in], B.blo, B.bhi, B.costs,
+			                   B.ctl, K);
+			if (levels < WIDE_LEVELS)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(sah_split_kernel<1024>), dim3(GRID / 4), dim3(1024), 0, nullptr, B.tasks[side_in], side_in, B.lists[side_in], B.blo, B.bhi,
+				                   B.costs, B.tasks[side_out], B.chunks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps, K);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(sah_split_kernel<256>), dim3(GRID), dim3(256), 0, nullptr, B.tasks[side_in], side_in, B.lists[side_in], B.blo, B.bhi, B.costs,
+				                   B.tasks[side_out], B.chunks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps, K);
+			side_in = side_out;
+			levels++;
+		}
+		KD_TRY(hipGetLastError());
+		KD_TRY(hipMemcpy(&ctl, B.ctl, sizeof ctl, hipMemcpyDeviceToHost));   // the look (synchronises)
+		if (ctl.error) { *overflow = true; return 0; }
+		done = ctl.side[side_in][0] == 0;
+		if (levels > K.max_depth + 2 * LEVELS_PER_LOOK + 2) { say(err, err_len, "SAH build did not terminate"); return HXR_E_INVALID; }
+	}
+	out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	out.levels = levels;
+	out.max_depth = (int)ctl.max_depth;
+	std::vector<hxr_kd_node> dev_nodes(ctl.node_cursor);
+	std::vector<int32_t> dev_leaf(ctl.leaf_cursor);
+	KD_TRY(hipMemcpy(dev_nodes.data(), B.nodes, dev_nodes.size() * sizeof(hxr_kd_node), hipMemcpyDeviceToHost));
+	if (!dev_leaf.empty()) KD_TRY(hipMemcpy(dev_leaf.data(), B.leaf, dev_leaf.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+	renumber(dev_nodes, dev_leaf, out);
 	return 0;
 }
 
@@ -444,6 +823,28 @@ int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, cons
 		if (!overflow) return 0;
 	}
 	say(err, err_len, "kd build: the tree of this mesh outgrows the build buffers (a degenerate mesh?)");
+	return HXR_E_INVALID;
+}
+
+int build_sah_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
+                   double traversal_cost, double intersect_cost, double empty_bonus, int max_depth, int min_leaf, DeviceBuiltTree& out, char* err, size_t err_len)
+{
+	if (num_triangles < 0 || num_triangles > (1ll << 24)) { say(err, err_len, "SAH build: %lld triangles not supported", (long long)num_triangles); return HXR_E_INVALID; }
+	const uint32_t n = (uint32_t)num_triangles;
+	const SahCosts K{traversal_cost, intersect_cost, empty_bonus, max_depth, min_leaf};
+	uint64_t scale = 1;
+	for (int tries = 0; tries < 4; tries++, scale *= 4) {
+		// a level's lists hold at most twice its parent level's; SAH trees of the reference's meshes end below 2 nodes and 4 leaf entries per triangle
+		const uint64_t tasks = std::min<uint64_t>((8ull * n + 4096) * scale, 1ull << 26), list = std::min<uint64_t>((16ull * n + 65536) * scale, 1ull << 29),
+		               nodes = std::min<uint64_t>((16ull * n + 4096) * scale, 1ull << 27), leaf = std::min<uint64_t>((16ull * n + 65536) * scale, 1ull << 30);
+		const uint64_t chunks = 3 * (2 * list / 256 + tasks) + 64;
+		SahCaps caps{(uint32_t)tasks, (uint32_t)(list - 1), (uint32_t)nodes, (uint32_t)(leaf - 1), (uint32_t)std::min<uint64_t>(chunks, 1ull << 30)};
+		bool overflow = false;
+		const int rc = sah_attempt(d_tris, n, d_vertices, bbox_min, bbox_max, caps, K, out, &overflow, err, err_len);
+		if (rc) return rc;
+		if (!overflow) return 0;
+	}
+	say(err, err_len, "SAH build: the tree of this mesh outgrows the build buffers (a degenerate mesh?)");
 	return HXR_E_INVALID;
 }
 

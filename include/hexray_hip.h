@@ -378,6 +378,11 @@ int hxr_sah_build(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int6
 int hxr_kd_build_device(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf_indices,
                         int64_t* num_nodes, int64_t* num_leaf_indices, int* max_depth, double* build_ms);
 
+/* The module's surface-area-heuristic tree (hxr_scene_options.accel = HXR_ACCEL_SAH) of one mesh, built by kernels: node for node the tree
+ * hxr_sah_build makes on the host.  Same arguments and conventions as hxr_kd_build_device. */
+int hxr_sah_build_device(const hxr_scene_desc* desc, int mesh, hxr_kd_node* nodes, int64_t max_nodes, int32_t* leaf_indices, int64_t max_leaf_indices,
+                        int64_t* num_nodes, int64_t* num_leaf_indices, int* max_depth, double* build_ms);
+
 /* Nodes / leaf entries / depth of the tree actually walked for mesh `mesh` (after an HXR_ACCEL_SAH rebuild these
  * differ from the descriptor's).  The reference prints the same statistics at load (src/mesh.cpp:39-47). */
 int hxr_scene_tree_stats(const hxr_scene* scene, int mesh, int64_t* nodes, int64_t* leaf_entries, int* max_depth);

@@ -132,3 +132,44 @@ def test_heightfield_prepared_on_the_gpu_from_the_raw_image(gpu):
     assert a["camera_samples"] == b["camera_samples"]
     for k in ("raycasts", "hf_calls", "hf_tri_tests"):
         assert abs(a[k] - b[k]) <= 2e-3 * b[k], (k, a[k], b[k])
+
+
+def test_device_sah_build_equals_host_sah_build_for_every_reference_mesh(gpu):
+    """The module's SAH tree (hxr_scene_options.accel = HXR_ACCEL_SAH) built by kernels (hxr_sah_build_device: every candidate plane's cost
+    counted independently, chunks of 256 candidates spread over the GPU) is the tree the host builder makes by sorting and sweeping
+    (hxr_sah_build): same split planes bit for bit, same leaf contents in the same order, same numbering -- for all nine reference meshes."""
+    hx = gpu
+    hs = hx.HostScene(ALL_MESHES)
+    desc = SceneDesc.from_address(hs.desc)
+    total_ms = 0.0
+    for mi in range(desc.num_meshes):
+        want_nodes, want_leaf, want_depth, _ = hx.sah_build(hs, mi, device=False)
+        nodes, leaf, depth, ms = hx.sah_build(hs, mi, device=True)
+        total_ms += ms
+        assert len(nodes) == len(want_nodes) and len(leaf) == len(want_leaf), (mi, len(nodes), len(want_nodes), len(leaf), len(want_leaf))
+        for field in ("axis", "first", "count", "parent"):
+            assert np.array_equal(nodes[field], want_nodes[field]), (mi, field)
+        assert np.array_equal(nodes["split"].view(np.uint64), want_nodes["split"].view(np.uint64)), mi
+        assert np.array_equal(leaf, want_leaf), mi
+        assert depth == want_depth
+    print("SAH trees of the nine reference meshes built on the device in %.2f ms" % total_ms)
+
+
+def test_sah_scene_built_on_the_device_renders_what_the_host_built_sah_scene_renders(gpu, monkeypatch):
+    """hxr_scene_create_ex with HXR_ACCEL_SAH builds its trees on the device by default; HXR_SAH_HOST=1 is the host builder: same trees,
+    so bit-identical frames and identical work counters."""
+    hx = gpu
+    ov = hx.overlay_text(width=480, height=270, dof=True, num_samples=4)
+    hs = hx.HostScene(scene_path("meshes.hexray"), ov)
+    p = hx.frame_params(collect_counters=True)
+    dev = hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
+    got = dev.render(p)
+    gc = dev.counters()
+    monkeypatch.setenv("HXR_SAH_HOST", "1")
+    host = hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
+    want = host.render(p)
+    wc = host.counters()
+    assert np.array_equal(got, want)
+    assert gc == wc
+    for mi in range(3):
+        assert dev.tree_stats(mi) == host.tree_stats(mi)

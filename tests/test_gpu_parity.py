@@ -250,6 +250,25 @@ def test_headline_scene_full_size_against_oracle_strip(gpu):
     for k in EXACT_COUNTERS:
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     ds.close()
+    sah_frame_against(hs, dict(mode=hx.MODE_ADAPTIVE_AA), g, o, oc)      # config 3a through the module's SAH trees (built on the device)
+
+
+SAH_EXACT = ("camera_samples", "raycasts", "shadow_queries", "node_tests", "tex_bilinear", "env_bilinear", "aa_pixels")
+
+
+def sah_frame_against(hs, fp, ref_tree_frame, oracle_frame, oc, exact=SAH_EXACT):
+    """The same full-size frame through HXR_ACCEL_SAH (trees built by kernels at hxr_scene_create_ex): the oracle's frame (it walks the
+    reference's trees) within the bar, the reference-tree GPU frame almost everywhere exactly, the same rays and shadow queries."""
+    sah = hx.DeviceScene(hs, accel=hx.ACCEL_SAH)
+    g = sah.render(hx.frame_params(collect_counters=True, **fp))
+    c = sah.counters()
+    assert np.all(rms(g, oracle_frame) <= RMS_BAR), rms(g, oracle_frame)
+    differing = int((np.abs(g - ref_tree_frame).max(axis=2) > 1e-5).sum())
+    assert differing <= max(2, g.shape[0] * g.shape[1] // 2000), differing   # ties on shared edges only
+    for k in exact:
+        assert c[k] == oc[k], (k, c[k], oc[k])
+    assert c["box_test_mismatch"] == 0 and c["tri_tests"] < oc["tri_tests"]
+    sah.close()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -605,6 +624,8 @@ def test_full_size_config_against_oracle(gpu, what, scene, ov, fp, exact):
     # data-dependent path lengths in the Monte-Carlo modes: a rounding-level difference may flip a cut-off; 1e-5 relative
     for k in ("raycasts", "shadow_queries", "node_tests"):
         assert abs(gc[k] - oc[k]) <= max(2, 1e-5 * oc[k]), (what, k, gc[k], oc[k])
+    if scene in ("simple.hexray", "meshes.hexray"):      # configs 2 and 3b at full size through the module's SAH trees as well
+        sah_frame_against(hx.HostScene(scene_path(scene), hx.overlay_text(**ov)), fp, g, o, oc, exact=("camera_samples",) if what.startswith("config3b") else SAH_EXACT)
 
 
 def test_smallpt_256_paths_accounting_and_determinism(gpu):
