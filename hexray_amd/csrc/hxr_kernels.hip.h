@@ -983,15 +983,31 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 					// fetch levels 0-7 at once and decide in registers (same comparisons, same order, same first failure)
 					const HXR_GLOBAL float* hm = in_hbm(F.high_map) + cell * 16;
 					typedef float Levels4 __attribute__((ext_vector_type(4)));
-					const Levels4 lo = *(const HXR_GLOBAL Levels4*)hm, hi = *(const HXR_GLOBAL Levels4*)(hm + 4);
-					const float lv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+					const Levels4 lo = *(const HXR_GLOBAL Levels4*)hm;
 					const int top = F.max_k < 8 ? F.max_k : 8;
-					bool passing = true;   // no branches between the levels: the lanes of a wave stop at different ones
+					bool passing = true;   // no branches between the levels of a group: the lanes of a wave stop at different ones
 					k = 1;
+					{
+						const float lv[4] = {lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
-					for (int j = 1; j < 8; j++) {
-						passing = passing & (j < top) & (p.y + step.y * (1 << j) > lv[j]);
-						k += passing ? 1 : 0;
+						for (int j = 1; j < 4; j++) {
+							passing = passing & (j < top) & (p.y + step.y * (1 << j) > lv[j]);
+							k += passing ? 1 : 0;
+						}
+					}
+#ifndef HXR_HF_ONE_STAGE
+					// two probes per step on average (hf_stats): levels 4..7 -- half of the record and of the comparisons -- only when some lane of the
+					// wave has passed level 3, i.e. is about to skip eight cells or more
+					if (hxr_ballot(passing))
+#endif
+					{
+						const Levels4 hi = *(const HXR_GLOBAL Levels4*)(hm + 4);
+						const float lv[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+						for (int j = 4; j < 8; j++) {
+							passing = passing & (j < top) & (p.y + step.y * (1 << j) > lv[j - 4]);
+							k += passing ? 1 : 0;
+						}
 					}
 					while (k >= 8 && k < F.max_k && p.y + step.y * (1 << k) > hm[k]) k++;
 					tl.add(HC_HFHIGH, k < F.max_k ? k : F.max_k - 1);   // probes made: every passed level plus the failed one
@@ -1577,6 +1593,13 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 	constexpr bool gather_records = gi;
 	constexpr bool rect = (F & HXR_F_RECT) != 0;   // RectLight code only where the scene has one
 	constexpr bool defer = (F & HXR_F_DEFER) != 0; // secondary rays go to the queue: `top` stays 0, the stack is never touched
+#ifdef HXR_LIGHTS_IN_REGS
+	constexpr bool lights_from_table = false;
+#else
+	// Whitted variants without RectLights: a light sample is the PointLight's position and colour -- functions of the light's index alone --
+	// so they are read from the light's record where they are used instead of living in nine vector registers across the traversal
+	constexpr bool lights_from_table = !gi && !rect;
+#endif
 	constexpr bool one = (F & HXR_F_STACK1) != 0;  // at most one pending ray: it waits in LDS (st.pend)
 	constexpr int lds_slots = (F & HXR_F_LDSSTACK) != 0 ? HXR_LDS_RAY_SLOTS : 0;   // stack entries 0 .. lds_slots-1 live in LDS (st.pend), the rest in `stack`
 	static_assert(lds_slots == 0 || (!gi && !glossy && !defer && !one), "the LDS stack entries are for the in-place Whitted variants without glossy generators");
