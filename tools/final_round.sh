@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one gpurun call: bench lines of every workload, the rocprof / PMC profile of the headline,
-# the 8-way shard bound, the interactive loop.  usage: tools/final_round.sh <tag>
-tag=${1:-r02}
+# Everything profiles/ holds for a round, in one gpurun call: bench lines of every workload, the rocprof / PMC profile of the headline and of
+# the other config kernels, the 8-way shard bounds, phase clocks, the interactive loop, scene preparation.  usage: tools/final_round.sh <tag>
+tag=${1:-r03}
 out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err
 : > $out/bench_all_workloads.jsonl
@@ -10,8 +10,11 @@ for w in meshes16 meshes_aa simple1 heightfield16 smallpt16 smallpt256 cornell16
 done
 timeout -k 10 300 python3 bench.py --accel sah --no-other-timings > $out/bench_sah.json 2>> $out/bench.err
 tools/profile_round.sh $tag > $out/profile.log 2>&1
+for w in heightfield16 cornell16 smallpt16; do tools/pmc.sh $w gpurun_out/$tag/pmc_$w > $out/pmc_$w.txt 2>&1; rm -rf $out/pmc_$w/pass*/; done
 HXR_TILE=8 HXR_ALL_RANKS=1 timeout -k 10 300 python3 tools/shard_time.py meshes16 > $out/shard_times_reference_tree.txt 2>&1
 HXR_ACCEL=sah HXR_TILE=8 HXR_ALL_RANKS=1 timeout -k 10 300 python3 tools/shard_time.py meshes16 > $out/shard_times_sah_tree.txt 2>&1
+HXR_TILE=8 HXR_ALL_RANKS=1 timeout -k 10 300 python3 tools/shard_time.py smallpt256 > $out/shard_times_smallpt256.txt 2>&1
+timeout -k 10 300 python3 tools/sah_build_times.py > $out/sah_build_times.txt 2>&1
 timeout -k 10 120 hexray_amd/bin/hexray data/simple.hexray --interactive 300 > $out/interactive_simple.txt 2>&1
 timeout -k 10 120 hexray_amd/bin/hexray data/simple.hexray --interactive 300 --fovea 75 >> $out/interactive_simple.txt 2>&1
 timeout -k 10 120 hexray_amd/bin/hexray data/meshes.hexray --width 1920 --height 1080 --dof on --spp 16 --frames 5 --devices 0,0 >> $out/interactive_simple.txt 2>&1
