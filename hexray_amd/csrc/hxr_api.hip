@@ -1169,6 +1169,16 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 			o.max_h = (const float*)pm;
 			o.high_map = (const float*)ph;
 		}
+		{   // the marcher's per-cell record {maxH, levels 1..3}, gathered from the two tables above (whoever made them)
+			const int cells = h.W * h.H;
+			void* pr = nullptr;
+			if (s->arena.alloc((size_t)cells * 4 * sizeof(float), &pr)) return fail();
+			const bool pyramid = o.use_optimization && o.max_k > 1;   // only then does validate() vouch for 16 floats per cell behind high_map
+			hipLaunchKernelGGL(hxr_hf_pack_kernel, dim3(std::min((cells + 255) / 256, 2048)), dim3(256), 0, nullptr, o.max_h, pyramid ? o.high_map : (const float*)nullptr, cells,
+			                   (float*)pr);
+			if (hipGetLastError() != hipSuccess) { set_err("heightfield table kernels failed to launch"); return fail(); }
+			o.step_rec = (const float*)pr;
+		}
 	}
 	if (s->arena.upload(hfs.data(), hfs.size(), &V.heightfields)) return fail();
 

@@ -976,19 +976,22 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 				marching = false;
 			} else {
 				const size_t cell = (size_t)z0 * F.W + x0;   // (x0, z0) is in range here: no clamping needed
-				const float cell_max = in_hbm(F.max_h)[cell];        // issued with the pyramid levels: one memory latency per step instead of one per level
+				// ONE 16-byte load per step: the cell's maxH and pyramid levels 1..3 (step_rec: a table of its own, a quarter of the pyramid's
+				// size, so that the dependent load of a marching step is served by L2)
+				typedef float Levels4 __attribute__((ext_vector_type(4)));
+				const Levels4 rec = *(const HXR_GLOBAL Levels4*)(in_hbm(F.step_rec) + cell * 4);
+				const float cell_max = rec.x;
 				int k = 0;
 				if (F.use_optimization && F.max_k > 1) {
-					// the reference probes levels 1, 2, ... one dependent load at a time; the levels of a cell are one 64-byte record, so
-					// fetch levels 0-7 at once and decide in registers (same comparisons, same order, same first failure)
+					// the reference probes levels 1, 2, ... one dependent load at a time; here levels 1-3 arrive with maxH and are decided in
+					// registers (same comparisons, same order, same first failure), levels 4-7 -- one more 16-byte read of the pyramid -- follow
+					// only when some lane got that far
 					const HXR_GLOBAL float* hm = in_hbm(F.high_map) + cell * 16;
-					typedef float Levels4 __attribute__((ext_vector_type(4)));
-					const Levels4 lo = *(const HXR_GLOBAL Levels4*)hm;
 					const int top = F.max_k < 8 ? F.max_k : 8;
 					bool passing = true;   // no branches between the levels of a group: the lanes of a wave stop at different ones
 					k = 1;
 					{
-						const float lv[4] = {lo.x, lo.y, lo.z, lo.w};
+						const float lv[4] = {0.0f, rec.y, rec.z, rec.w};
 #pragma unroll
 						for (int j = 1; j < 4; j++) {
 							passing = passing & (j < top) & (p.y + step.y * (1 << j) > lv[j]);
@@ -2602,6 +2605,18 @@ __global__ void hxr_hf_normals_kernel(const float* __restrict__ heights, int W, 
 		normals[(size_t)i * 3 + 0] = n[0];
 		normals[(size_t)i * 3 + 1] = n[1];
 		normals[(size_t)i * 3 + 2] = n[2];
+	}
+}
+
+// The marcher's per-cell record: {maxH, highMap levels 1, 2, 3} (HxrHeightfieldDev::step_rec)
+// (`high_map` is null for a heightfield without the pyramid -- useOptimization off: the descriptor then carries no such table)
+__global__ void hxr_hf_pack_kernel(const float* __restrict__ max_h, const float* __restrict__ high_map, int cells, float* __restrict__ rec)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) {
+		rec[(size_t)i * 4 + 0] = max_h[i];
+		rec[(size_t)i * 4 + 1] = high_map ? high_map[(size_t)i * 16 + 1] : 0.0f;
+		rec[(size_t)i * 4 + 2] = high_map ? high_map[(size_t)i * 16 + 2] : 0.0f;
+		rec[(size_t)i * 4 + 3] = high_map ? high_map[(size_t)i * 16 + 3] : 0.0f;
 	}
 }
 
