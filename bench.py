@@ -332,7 +332,7 @@ def main():
             # the same preparation with Mesh::buildKD and Heightfield::fillProperties (blur, box, normals, maxima)
             # left to the module, which runs them as kernels inside hxr_scene_create
             t_prep = time.perf_counter()
-            bare = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov), gpu_kd_build=True, gpu_heightfield_blur=True)
+            bare = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov), gpu_kd_build=True, gpu_heightfield_blur=True, gpu_bitmap_prep=True)
             t_mid = time.perf_counter()
             hx.DeviceScene(bare, accel=hx.ACCEL_REFERENCE_DEVICE_BUILD).close()
             result["scene_prep_s"]["prepared_on_gpu"] = {"host_parse_flatten": round(t_mid - t_prep, 3),

@@ -134,16 +134,17 @@ class HostScene:
     """
 
     def __init__(self, path: str, overlay: str = "", gpu_heightfield_tables: bool = False, gpu_kd_build: bool = False,
-                 gpu_prepare_triangles: bool = False, gpu_heightfield_blur: bool = False):
+                 gpu_prepare_triangles: bool = False, gpu_heightfield_blur: bool = False, gpu_bitmap_prep: bool = False):
         """``gpu_heightfield_tables``: leave the heightfield maxima tables to the render module (it builds them on the GPU); such a
         scene is for the HIP module only -- the CPU oracle needs the host's tables.
         ``gpu_kd_build``: skip Mesh::buildKD on the host; create the DeviceScene with ACCEL_REFERENCE_DEVICE_BUILD (or ACCEL_SAH).
         ``gpu_prepare_triangles``: skip Mesh::prepareTriangles; create the DeviceScene with ``device_prepare_triangles=True``.
-        ``gpu_heightfield_blur``: leave a heightfield's blur, bounding box, normals and maxima tables to the render module."""
+        ``gpu_heightfield_blur``: leave a heightfield's blur, bounding box, normals and maxima tables to the render module.
+        ``gpu_bitmap_prep``: leave Bitmap::decompressGamma / Bitmap::differentiate to the render module (hxr_bitmap.prep)."""
         lib = host_lib()
         err = ctypes.create_string_buffer(1024)
         self._h = lib.hxh_scene_load_ex(os.fsencode(path), overlay.encode(), (1 if gpu_heightfield_tables else 0) | (2 if gpu_kd_build else 0) | (4 if gpu_prepare_triangles else 0)
-                                        | (8 if gpu_heightfield_blur else 0),
+                                        | (8 if gpu_heightfield_blur else 0) | (16 if gpu_bitmap_prep else 0),
                                         err, len(err))
         if not self._h:
             raise ValueError(f"cannot load scene {path}: {err.value.decode(errors='replace')}")

@@ -92,6 +92,7 @@ struct hxr_scene {
 	std::vector<TreeStats> tree_stats;   // per mesh: the tree actually walked
 	double kd_build_ms = 0;              // HXR_ACCEL_REFERENCE_DEVICE_BUILD: time of the kd builds on the GPU, all meshes
 	const hxr_triangle* d_triangles = nullptr;   // the triangle records in HBM (hxr_scene_verify_tables reads them back)
+	std::vector<int> bitmap_prep;        // per bitmap: hxr_bitmap::prep it was created from (| 4: gamma curve evaluated on the device)
 	std::vector<char> hf_raw;            // per heightfield: created from hxr_heightfield::raw_heights (blur / box / normals computed here)
 	// per-frame scratch, grown on demand
 	float* d_frame = nullptr;       size_t frame_bytes = 0;    // hxr_render staging / AA scratch frame
@@ -260,6 +261,11 @@ int validate(const hxr_scene_desc* d)
 		const int64_t floats = (int64_t)b.width * b.height * 3;
 		if (b.width < 0 || b.height < 0 || b.first_texel < 0 || b.first_texel > d->f32_pool_size || floats > d->f32_pool_size - b.first_texel) {
 			set_err("bitmap %lld: texels outside the descriptor", (long long)i);
+			return HXR_E_INVALID;
+		}
+		if ((b.prep & ~(HXR_BITMAP_GAMMA | HXR_BITMAP_DIFFERENTIATE)) != 0 || ((b.prep & HXR_BITMAP_GAMMA) && !(b.gamma > 0 && b.gamma <= 100.0f)) ||
+		    ((b.prep & HXR_BITMAP_GAMMA) && b.first_gamma_table != -1 && (b.first_gamma_table < 0 || b.first_gamma_table > d->f32_pool_size - 256))) {
+			set_err("bitmap %lld: bad prep / gamma / gamma table", (long long)i);
 			return HXR_E_INVALID;
 		}
 	}
@@ -1183,10 +1189,29 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (s->arena.upload(hfs.data(), hfs.size(), &V.heightfields)) return fail();
 
 	std::vector<HxrBitmapDev> bms((size_t)d->num_bitmaps);
+	s->bitmap_prep.assign((size_t)d->num_bitmaps, 0);
 	for (int64_t i = 0; i < d->num_bitmaps; i++) {
 		bms[(size_t)i].width = d->bitmaps[i].width;
 		bms[(size_t)i].height = d->bitmaps[i].height;
 		bms[(size_t)i].texels = d_f32 + d->bitmaps[i].first_texel;
+		const hxr_bitmap& b = d->bitmaps[i];
+		const size_t texels = (size_t)b.width * b.height;
+		s->bitmap_prep[(size_t)i] = b.prep | (b.first_gamma_table < 0 && (b.prep & HXR_BITMAP_GAMMA) ? 4 : 0);
+		if (!b.prep || texels == 0) continue;
+		// hxr_bitmap::prep: the loader's passes over the file's texels, here as kernels on the uploaded pool (in place; the derivative
+		// reads neighbours, so it goes to a second table)
+		float* t = const_cast<float*>(d_f32) + b.first_texel;
+		const int grid = (int)std::min<size_t>((texels * 3 + 255) / 256, 4096);
+		if (b.prep & HXR_BITMAP_GAMMA)
+			hipLaunchKernelGGL(hxr_bitmap_gamma_kernel, dim3(grid), dim3(256), 0, nullptr, t, texels * 3, b.first_gamma_table >= 0 ? d_f32 + b.first_gamma_table : (const float*)nullptr,
+			                   fabsf(b.gamma - 2.2f) < 1e-6f ? 1 : 0, b.gamma);
+		if (b.prep & HXR_BITMAP_DIFFERENTIATE) {
+			void* pd = nullptr;
+			if (s->arena.alloc(texels * 3 * sizeof(float), &pd)) return fail();
+			hipLaunchKernelGGL(hxr_bitmap_differentiate_kernel, dim3(grid), dim3(256), 0, nullptr, (const float*)t, b.width, b.height, (float*)pd);
+			bms[(size_t)i].texels = (const float*)pd;
+		}
+		if (hipGetLastError() != hipSuccess) { set_err("bitmap preparation kernels failed to launch"); return fail(); }
 	}
 	if (s->arena.upload(bms.data(), bms.size(), &V.bitmaps)) return fail();
 
@@ -1792,6 +1817,25 @@ int hxr_scene_verify_tables(const hxr_scene* s, const hxr_scene_desc* d, int64_t
 			}
 			for (int k = 0; k < 3; k++)
 				if (!(std::fabs(hfs[(size_t)i].bbox_min[k] - h.bbox_min[k]) <= tol) || !(std::fabs(hfs[(size_t)i].bbox_max[k] - h.bbox_max[k]) <= tol)) ++*mismatches;
+		}
+	}
+	// bitmaps the module decoded / differentiated itself (hxr_bitmap::prep) against the complete descriptor's: bit for bit, except where the
+	// gamma curve had no host table (float texels: the device's powf, compared to 4 ulp-ish of the value)
+	std::vector<HxrBitmapDev> bms((size_t)d->num_bitmaps);
+	if (d->num_bitmaps) HIP_TRY(hipMemcpy(bms.data(), V.bitmaps, bms.size() * sizeof(HxrBitmapDev), hipMemcpyDeviceToHost));
+	for (int64_t i = 0; i < d->num_bitmaps; i++) {
+		if ((size_t)i >= s->bitmap_prep.size() || !s->bitmap_prep[(size_t)i]) continue;
+		const hxr_bitmap& b = d->bitmaps[i];
+		if (b.prep) continue;   // `desc` is not the complete one for this bitmap
+		if (b.width != bms[(size_t)i].width || b.height != bms[(size_t)i].height) { ++*mismatches; continue; }
+		std::vector<float> got((size_t)b.width * b.height * 3);
+		if (got.empty()) continue;
+		HIP_TRY(hipMemcpy(got.data(), bms[(size_t)i].texels, got.size() * sizeof(float), hipMemcpyDeviceToHost));
+		const float* want = d->f32_pool + b.first_texel;
+		const bool curve = (s->bitmap_prep[(size_t)i] & 4) != 0;
+		for (size_t k = 0; k < got.size(); k++) {
+			const bool same = curve ? std::fabs(got[k] - want[k]) <= 1e-6f * std::max(1.0f, std::fabs(want[k])) : memcmp(&got[k], &want[k], sizeof(float)) == 0;
+			if (!same) ++*mismatches;
 		}
 	}
 	return 0;

@@ -2608,6 +2608,42 @@ __global__ void hxr_hf_normals_kernel(const float* __restrict__ heights, int W, 
 	}
 }
 
+// hxr_bitmap::prep -- the loader's two passes over a bitmap (src/bitmap.cpp:304-338), one channel value / one texel per lane.
+// Bitmap::decompressGamma: a channel c > 0 becomes decompress_sRGB(c) (src/color.h:49-57) when the gamma is 2.2, pow(c, gamma) otherwise.
+// `table` (an 8-bit source: the host's decode of q / 255.0f, q = 0..255) makes the result the host's bit for bit; without one
+// (float texels) the curve is evaluated here, by the device's powf.
+__global__ void hxr_bitmap_gamma_kernel(float* __restrict__ texels, size_t n, const float* __restrict__ table, int srgb, float gamma)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const float c = texels[i];
+		if (!(c > 0)) continue;
+		float v;
+		if (table) v = table[min(max((int)(c * 255.0f + 0.5f), 0), 255)];
+		else if (!srgb) v = powf(c, gamma);
+		else v = c >= 1 ? c : c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+		texels[i] = v;
+	}
+}
+
+// Bitmap::differentiate: texel (x, y) becomes (I(x, y) - I(x + 1, y), I(x, y) - I(x, y + 1), 0) with wrap-around neighbours and
+// I = Color::intensity = (r + g + b) / 3 -- which the reference's Release flags (-ffast-math: reciprocal-math) and the host loader built
+// with them compile to a multiplication by the float nearest 1/3; so does this kernel, to be the host's table bit for bit.
+__global__ void hxr_bitmap_differentiate_kernel(const float* __restrict__ src, int W, int H, float* __restrict__ dst)
+{
+#pragma clang fp contract(off)
+	const float third = 1.0f / 3.0f;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * H; i += gridDim.x * blockDim.x) {
+		const int x = i % W, y = i / W;
+		const float* a = src + (size_t)i * 3;
+		const float* bx = src + ((size_t)y * W + (x + 1) % W) * 3;
+		const float* by = src + ((size_t)((y + 1) % H) * W + x) * 3;
+		const float here = ((a[0] + a[1]) + a[2]) * third;
+		dst[(size_t)i * 3 + 0] = here - ((bx[0] + bx[1]) + bx[2]) * third;
+		dst[(size_t)i * 3 + 1] = here - ((by[0] + by[1]) + by[2]) * third;
+		dst[(size_t)i * 3 + 2] = 0.0f;
+	}
+}
+
 // The marcher's per-cell record: {maxH, highMap levels 1, 2, 3} (HxrHeightfieldDev::step_rec)
 // (`high_map` is null for a heightfield without the pyramid -- useOptimization off: the descriptor then carries no such table)
 __global__ void hxr_hf_pack_kernel(const float* __restrict__ max_h, const float* __restrict__ high_map, int cells, float* __restrict__ rec)

@@ -65,15 +65,35 @@ struct Loader {
 		return full;
 	}
 
-	int add_bitmap(const Image& img)
+	int add_bitmap(const Image& img, int prep = 0, float gamma = 1.0f)
 	{
 		hxr_bitmap bm;
 		bm.width = img.ok() ? img.w : 0;
 		bm.height = img.ok() ? img.h : 0;
 		bm.first_texel = int64_t(fs.f32_pool.size());
+		bm.prep = img.ok() ? prep : 0;
+		bm.gamma = gamma;
+		bm.first_gamma_table = -1;
 		if (img.ok()) fs.f32_pool.insert(fs.f32_pool.end(), img.rgb.begin(), img.rgb.end());
+		if (bm.prep & HXR_BITMAP_GAMMA) {
+			float table[256];
+			if (gamma_table(img, gamma, table)) {
+				bm.first_gamma_table = int64_t(fs.f32_pool.size());
+				fs.f32_pool.insert(fs.f32_pool.end(), table, table + 256);
+			}
+		}
 		fs.bitmaps.push_back(bm);
 		return int(fs.bitmaps.size()) - 1;
+	}
+
+	// A bitmap whose loader passes (Bitmap::decompressGamma / Bitmap::differentiate) run here, or -- FlatScene::gpu_bitmap_prep -- are
+	// left to the render module (hxr_bitmap::prep)
+	int add_prepared_bitmap(Image& img, float gamma, bool differentiated)
+	{
+		int prep = 0;
+		if (gamma != 1.0f) { if (fs.gpu_bitmap_prep) prep |= HXR_BITMAP_GAMMA; else decode_gamma(img, gamma); }
+		if (differentiated) { if (fs.gpu_bitmap_prep) prep |= HXR_BITMAP_DIFFERENTIATE; else differentiate(img); }
+		return add_bitmap(img, prep, gamma);
 	}
 
 	int64_t add_vectors(const std::vector<V3>& v)
@@ -154,8 +174,7 @@ struct Loader {
 					if (file_exists(fn) && load_image(fn, img)) break;
 				}
 				if (!img.ok()) { all_ok = false; break; }
-				if (gamma != 1.0f) decode_gamma(img, gamma);
-				env.side_bitmap[n] = add_bitmap(img);
+				env.side_bitmap[n] = add_prepared_bitmap(img, gamma, false);
 			}
 		env.loaded = all_ok ? 1 : 0;
 		if (!all_ok) {
@@ -320,8 +339,7 @@ struct Loader {
 			load_image(fn, img);
 			float gamma = 1.0f;
 			b.get_float("assumedGamma", gamma, 0.1f, 100.0f);
-			if (gamma != 1.0f) decode_gamma(img, gamma);
-			t.bitmap = add_bitmap(img);
+			t.bitmap = add_prepared_bitmap(img, gamma, false);
 		} else if (b.cls == "Fresnel") {        // src/shading.h:179-187
 			t.type = HXR_TEX_FRESNEL;
 			t.ior = 1.33;
@@ -337,8 +355,7 @@ struct Loader {
 			if (!present) b.require("file");
 			Image img;
 			load_image(fn, img);
-			differentiate(img);
-			t.bitmap = add_bitmap(img);
+			t.bitmap = add_prepared_bitmap(img, 1.0f, true);
 		} else if (b.cls == "Bumps") {          // src/shading.h:217-227 (strength is a float there)
 			t.type = HXR_TEX_BUMPS;
 			float s = 1;
@@ -550,7 +567,7 @@ void FlatScene::refresh_desc()
 #undef HXH_TABLE
 }
 
-std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build, bool gpu_prepare_triangles, bool gpu_heightfield_blur)
+std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables, bool gpu_kd_build, bool gpu_prepare_triangles, bool gpu_heightfield_blur, bool gpu_bitmap_prep)
 {
 	std::ifstream in(scene_path);
 	if (!in) throw std::runtime_error("Cannot open scene file `" + scene_path + "'!");
@@ -562,6 +579,7 @@ std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::
 	auto fs = std::make_unique<FlatScene>();
 	fs->gpu_heightfield_tables = gpu_heightfield_tables || gpu_heightfield_blur;
 	fs->gpu_heightfield_blur = gpu_heightfield_blur;
+	fs->gpu_bitmap_prep = gpu_bitmap_prep;
 	fs->gpu_kd_build = gpu_kd_build;
 	fs->gpu_prepare_triangles = gpu_prepare_triangles;
 	// defaults, src/scene.h:244-269

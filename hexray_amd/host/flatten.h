@@ -58,6 +58,7 @@ struct FlatScene {
 	bool gpu_heightfield_blur = false;     // hxr_heightfield::raw_heights: blur, box, normals and maxima tables are all left to the render module
 	bool gpu_heightfield_tables = false;   // leave maxH / highMap to the render module (hxr_heightfield::first_maxh = first_highmap = -1)
 	bool gpu_prepare_triangles = false;    // leave Mesh::prepareTriangles to the render module (derived hxr_triangle fields zero)
+	bool gpu_bitmap_prep = false;          // leave Bitmap::decompressGamma / Bitmap::differentiate to the render module (hxr_bitmap::prep)
 	bool gpu_kd_build = false;             // leave Mesh::buildKD to the render module (hxr_mesh::num_kd_nodes = 0 with has_kd = 1)
 	hxr_scene_desc desc;
 	void refresh_desc();     // point desc at the vectors
@@ -68,7 +69,7 @@ struct FlatScene {
 // `gpu_heightfield_tables`: do not build the heightfield maxima tables on the host (the render module builds them on the GPU).
 // `gpu_kd_build`: do not build the meshes' kd-trees on the host (create the device scene with HXR_ACCEL_REFERENCE_DEVICE_BUILD).
 std::unique_ptr<FlatScene> load_scene(const std::string& scene_path, const std::string& overlay_text, bool gpu_heightfield_tables = false, bool gpu_kd_build = false,
-                                      bool gpu_prepare_triangles = false, bool gpu_heightfield_blur = false);
+                                      bool gpu_prepare_triangles = false, bool gpu_heightfield_blur = false, bool gpu_bitmap_prep = false);
 
 // The reference's zig-zag bucket list (src/sdl.cpp:280-294): rects as x0,y0,x1,y1.
 std::vector<int> bucket_list(int width, int height, int bucket_size);

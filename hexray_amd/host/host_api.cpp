@@ -26,7 +26,7 @@ hxh_scene* hxh_scene_load_ex(const char* scene_path, const char* overlay_text, u
 {
 	try {
 		auto fs = hxh::load_scene(scene_path ? scene_path : "", overlay_text ? overlay_text : "", (flags & HXH_GPU_HEIGHTFIELD_TABLES) != 0, (flags & HXH_GPU_KD_BUILD) != 0,
-		                          (flags & HXH_GPU_PREPARE_TRIANGLES) != 0, (flags & HXH_GPU_HEIGHTFIELD_BLUR) != 0);
+		                          (flags & HXH_GPU_PREPARE_TRIANGLES) != 0, (flags & HXH_GPU_HEIGHTFIELD_BLUR) != 0, (flags & HXH_GPU_BITMAP_PREP) != 0);
 		hxh_scene* s = new hxh_scene;
 		s->fs = std::move(fs);
 		return s;

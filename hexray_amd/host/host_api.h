@@ -27,7 +27,9 @@ hxh_scene* hxh_scene_load(const char* scene_path, const char* overlay_text, char
  * autoSmooth meshes, whose smoothing reads gnormal) and hxr_scene_options.device_prepare_triangles must be set when the device scene is created. */
 /*        HXH_GPU_HEIGHTFIELD_BLUR = leave ALL of a heightfield's preparation after the image load to the render module (hxr_heightfield::raw_heights):
  * Gaussian blur, bounding box, normals and maxima tables (src/heightfield.cpp:173-261); implies HXH_GPU_HEIGHTFIELD_TABLES. */
-enum { HXH_GPU_HEIGHTFIELD_TABLES = 1u, HXH_GPU_KD_BUILD = 2u, HXH_GPU_PREPARE_TRIANGLES = 4u, HXH_GPU_HEIGHTFIELD_BLUR = 8u };
+/*        HXH_GPU_BITMAP_PREP = hand bitmaps over as their files hold them and leave Bitmap::decompressGamma (BitmapTexture / cubemap assumedGamma) and
+ * Bitmap::differentiate (BumpTexture) to the render module (hxr_bitmap::prep; src/bitmap.cpp:304-338). */
+enum { HXH_GPU_HEIGHTFIELD_TABLES = 1u, HXH_GPU_KD_BUILD = 2u, HXH_GPU_PREPARE_TRIANGLES = 4u, HXH_GPU_HEIGHTFIELD_BLUR = 8u, HXH_GPU_BITMAP_PREP = 16u };
 hxh_scene* hxh_scene_load_ex(const char* scene_path, const char* overlay_text, unsigned flags, char* err, size_t err_len);
 const hxr_scene_desc* hxh_scene_desc(const hxh_scene* s);
 void hxh_scene_free(hxh_scene* s);

@@ -132,21 +132,34 @@ static void decode_span(float* p, size_t n, bool srgb, float gamma)
 	}
 }
 
+static bool eight_bit(const Image& img)
+{
+	float key[256];
+	for (int q = 0; q < 256; q++) key[q] = q / 255.0f;
+	for (float c : img.rgb) {
+		// range first: converting a NaN, an infinity or a huge texel of a float source to int is undefined behaviour
+		if (!(c >= 0.0f && c <= 1.0f)) return false;
+		const int q = (int)(c * 255.0f + 0.5f);
+		if (!(q >= 0 && q < 256 && key[q] == c)) return false;
+	}
+	return true;
+}
+
+bool gamma_table(const Image& img, float gamma, float table[256])
+{
+	if (!eight_bit(img)) return false;
+	for (int q = 0; q < 256; q++) table[q] = q / 255.0f;
+	decode_span(table, 256, fabsf(gamma - 2.2f) < 1e-6f, gamma);
+	return true;
+}
+
 void decode_gamma(Image& img, float gamma)
 {
-	const bool srgb = fabsf(gamma - 2.2f) < 1e-6f;
 	// The texels of an 8-bit image are one of 256 values (q / 255.0f): decode each once, through the same loop (this build's -ffast-math
 	// lets the compiler vectorise powf, whose lanes round like each other but not like the scalar function: going through the one loop
 	// keeps every texel what the straight pass gave it).  An image with any other value (an EXR source) takes the straight pass.
-	float key[256], val[256];
-	for (int q = 0; q < 256; q++) key[q] = val[q] = q / 255.0f;
-	for (float c : img.rgb) {
-		// range first: converting a NaN, an infinity or a huge texel of a float source to int is undefined behaviour
-		if (!(c >= 0.0f && c <= 1.0f)) { decode_span(img.rgb.data(), img.rgb.size(), srgb, gamma); return; }
-		const int q = (int)(c * 255.0f + 0.5f);
-		if (!(q >= 0 && q < 256 && key[q] == c)) { decode_span(img.rgb.data(), img.rgb.size(), srgb, gamma); return; }
-	}
-	decode_span(val, 256, srgb, gamma);
+	float val[256];
+	if (!gamma_table(img, gamma, val)) { decode_span(img.rgb.data(), img.rgb.size(), fabsf(gamma - 2.2f) < 1e-6f, gamma); return; }
 	for (float& c : img.rgb) c = val[(int)(c * 255.0f + 0.5f)];
 }
 

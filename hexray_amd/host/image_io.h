@@ -22,6 +22,8 @@ bool load_bmp(const std::string& path, Image& out);
 bool load_exr(const std::string& path, Image& out);       // scanline HALF/FLOAT, NONE/ZIP/ZIPS/PIZ; see exr_reader.cpp
 bool load_image(const std::string& path, Image& out);     // by extension, like Bitmap::loadImage
 void decode_gamma(Image& img, float gamma);               // Bitmap::decompressGamma
+// The 256 values decode_gamma gives the texels q / 255.0f of an 8-bit image (hxr_bitmap::first_gamma_table); false when `img` holds any other value
+bool gamma_table(const Image& img, float gamma, float table[256]);
 void differentiate(Image& img);                           // Bitmap::differentiate
 
 // 8-bit sRGB through the 4097-entry table, exactly as Color::toRGB32 does

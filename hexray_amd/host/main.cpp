@@ -77,7 +77,7 @@ int main(int argc, char** argv)
 
 	char err[1024] = "";
 	// the module builds the heightfield maxima tables on the GPU, and with --accel device-build the kd-trees (Mesh::buildKD) as well
-	const unsigned load_flags = HXH_GPU_HEIGHTFIELD_TABLES | (opt.accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD ? HXH_GPU_KD_BUILD : 0u) | (gpu_blur ? HXH_GPU_HEIGHTFIELD_BLUR : 0u);
+	const unsigned load_flags = HXH_GPU_HEIGHTFIELD_TABLES | HXH_GPU_BITMAP_PREP | (opt.accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD ? HXH_GPU_KD_BUILD : 0u) | (gpu_blur ? HXH_GPU_HEIGHTFIELD_BLUR : 0u);
 	hxh_scene* hs = hxh_scene_load_ex(scene.c_str(), overlay.c_str(), load_flags, err, sizeof err);
 	if (!hs) {
 		printf("Could not parse the scene file (%s)!\n%s\n", scene.c_str(), err);

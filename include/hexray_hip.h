@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HXR_ABI_VERSION 2u   /* 2: hxr_heightfield grew raw_heights / blur_radius / first_blur_kernel */
+#define HXR_ABI_VERSION 3u   /* 2: hxr_heightfield grew raw_heights / blur_radius / first_blur_kernel; 3: hxr_bitmap grew prep / gamma / first_gamma_table */
 
 /* ------------------------------------------------------------------ error codes */
 enum {
@@ -121,9 +121,23 @@ typedef struct hxr_heightfield {
 } hxr_heightfield;
 
 /* Bitmap (reference src/bitmap.h:32-63): float RGB texels, row-major, 3 floats per texel. */
+enum hxr_bitmap_prep {
+	HXR_BITMAP_GAMMA = 1,          /* Bitmap::decompressGamma (src/bitmap.cpp:321-338) is still to be applied */
+	HXR_BITMAP_DIFFERENTIATE = 2   /* Bitmap::differentiate (src/bitmap.cpp:304-319) is still to be applied (after the gamma decode, if both) */
+};
+
 typedef struct hxr_bitmap {
 	int32_t width, height;
 	int64_t first_texel;     /* f32_pool index of texel (0,0).r */
+	/* prep != 0: the texels are the FILE's, and the loader's passes over them named by `prep` are left to the module, which runs them
+	   as kernels at hxr_scene_create.  For the HIP module only (the oracle refuses such a descriptor).
+	   Gamma decode: a texel c > 0 becomes decompress_sRGB(c) when |gamma - 2.2| < 1e-6, pow(c, gamma) otherwise.  An 8-bit source has 256
+	   distinct texel values q / 255.0f: the host decodes those once (its own powf) into `first_gamma_table` (f32_pool, 256 entries:
+	   entry q = the decoded q / 255.0f) and the kernel looks every texel up -- bit-identical to the host's pass over the image.
+	   first_gamma_table = -1 (a float source, e.g. EXR): the kernel evaluates the curve itself (device powf: equal to float rounding). */
+	int32_t prep;
+	float gamma;
+	int64_t first_gamma_table;
 } hxr_bitmap;
 
 enum hxr_texture_type {
@@ -392,7 +406,8 @@ int hxr_scene_tree_stats(const hxr_scene* scene, int mesh, int64_t* nodes, int64
  * re-derived from `desc`, the maxima tables are compared with the ones `desc` carries (pass the complete descriptor here).
  * *mismatches receives the number of differing records / values: the preparation is pure copies and maxima, so it must be 0.
  * A scene created from hxr_heightfield::raw_heights is compared (heights, box, normals, maxima) with a tolerance of 1e-5 of the height range:
- * its blur adds the same taps in another order than the host's. */
+ * its blur adds the same taps in another order than the host's.  Bitmaps created from hxr_bitmap::prep are compared bit for bit with the
+ * descriptor's decoded / differentiated texels (to 1e-6 where the gamma curve had no host table). */
 int hxr_scene_verify_tables(const hxr_scene* scene, const hxr_scene_desc* desc, int64_t* mismatches);
 
 /* Per-frame camera update (Camera::beginFrame, src/camera.cpp:30-63, after move/rotate). */

@@ -1165,6 +1165,8 @@ int hxo_render(const hxr_scene_desc* sc, const hxr_frame_params* fp, float* out,
 	if (!sc || !fp || !out || sc->abi_version != HXR_ABI_VERSION) return -1;
 	for (int64_t i = 0; i < sc->num_heightfields; i++)
 		if (sc->heightfields[i].raw_heights || sc->heightfields[i].first_maxh < 0) return -1;   /* a descriptor whose tables were left to the GPU module */
+	for (int64_t i = 0; i < sc->num_bitmaps; i++)
+		if (sc->bitmaps[i].prep) return -1;                                                     /* likewise: gamma decode / differentiate left to it */
 	int W = fp->width > 0 ? fp->width : sc->settings.frame_width;
 	int H = fp->height > 0 ? fp->height : sc->settings.frame_height;
 	if (W <= 0 || H <= 0 || W > 1920 || H > 1920) return -1;

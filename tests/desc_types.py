@@ -38,7 +38,7 @@ class Heightfield(ctypes.Structure):
 
 
 class Bitmap(ctypes.Structure):
-    _fields_ = [("width", c_int32), ("height", c_int32), ("first_texel", c_int64)]
+    _fields_ = [("width", c_int32), ("height", c_int32), ("first_texel", c_int64), ("prep", c_int32), ("gamma", ctypes.c_float), ("first_gamma_table", c_int64)]
 
 
 class Texture(ctypes.Structure):

@@ -173,3 +173,38 @@ def test_sah_scene_built_on_the_device_renders_what_the_host_built_sah_scene_ren
     assert gc == wc
     for mi in range(3):
         assert dev.tree_stats(mi) == host.tree_stats(mi)
+
+
+@pytest.mark.parametrize("name", ["meshes.hexray", "boxed.hexray", "bumpmap.hexray"])
+def test_bitmaps_decoded_and_differentiated_on_the_gpu(gpu, name):
+    """hxr_bitmap::prep: Bitmap::decompressGamma (BitmapTexture / cubemap assumedGamma) and Bitmap::differentiate (BumpTexture) as kernels at
+    hxr_scene_create (src/bitmap.cpp:304-338).  8-bit sources are decoded through the host's 256-entry table and the derivative is plain
+    float arithmetic, so the tables must be the host loader's bit for bit -- and the frame the same frame."""
+    hx = gpu
+    ov = hx.overlay_text(width=320, height=240)
+    full = hx.HostScene(scene_path(name), ov)
+    bare = hx.HostScene(scene_path(name), ov, gpu_bitmap_prep=True)
+    d = SceneDesc.from_address(bare.desc)
+    assert any(d.bitmaps[i].prep for i in range(d.num_bitmaps))
+    ds = hx.DeviceScene(bare)
+    assert ds.verify_tables(full) == 0
+    p = hx.frame_params()
+    assert np.array_equal(ds.render(p), hx.DeviceScene(full).render(p))
+
+
+def test_gamma_curve_on_the_device_for_float_texels(gpu):
+    """A bitmap whose texels are not 8-bit values (an EXR source) carries no decode table (first_gamma_table = -1): the kernel evaluates
+    decompress_sRGB / pow itself.  Built here from boxed.hexray's descriptors: the table reference is dropped from the prep descriptor, and
+    the module's texels must then agree with the host's to float rounding (hxr_scene_verify_tables allows 1e-6 there; the table path allows 0)."""
+    hx = gpu
+    for name in ("boxed.hexray", "meshes.hexray"):      # gamma 1.5 (pow) and 2.2 (the sRGB curve)
+        full = hx.HostScene(scene_path(name))
+        bare = hx.HostScene(scene_path(name), gpu_bitmap_prep=True)
+        d = SceneDesc.from_address(bare.desc)
+        n = 0
+        for i in range(d.num_bitmaps):
+            if d.bitmaps[i].prep & 1:
+                d.bitmaps[i].first_gamma_table = -1
+                n += 1
+        assert n
+        assert hx.DeviceScene(bare).verify_tables(full) == 0

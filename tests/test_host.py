@@ -266,3 +266,39 @@ def test_heightfield_blur_below_one_sixth_flattens_the_field_on_both_paths():
         heights = np.ctypeslib.as_array(d.f32_pool, shape=(d.f32_pool_size,))[f.first_height:f.first_height + n]
         assert not heights.any()
     assert desc_of(raw).heightfields[0].raw_heights == 1 and desc_of(raw).heightfields[0].blur_radius == 0
+
+
+def test_bitmap_passes_left_to_the_module():
+    """HXH_GPU_BITMAP_PREP: bitmaps are handed over as their files hold them, flagged with the passes still due (hxr_bitmap::prep) and, for 8-bit
+    sources, the 256-entry decode table; the rest of the descriptor is unchanged.  Applying the passes here (numpy) gives the complete
+    descriptor's texels bit for bit: gamma by table look-up, Bitmap::differentiate (src/bitmap.cpp:304-319) with the Release build's
+    intensity = (r + g + b) * (1/3)."""
+    seen = set()
+    for name in ("meshes.hexray", "boxed.hexray", "bumpmap.hexray"):
+        full_scene, bare_scene = hx.HostScene(scene_path(name)), hx.HostScene(scene_path(name), gpu_bitmap_prep=True)
+        full, bare = desc_of(full_scene), desc_of(bare_scene)
+        assert full.num_bitmaps == bare.num_bitmaps and full.num_textures == bare.num_textures and full.num_triangles == bare.num_triangles
+        fpool = np.ctypeslib.as_array(full.f32_pool, shape=(full.f32_pool_size,))
+        bpool = np.ctypeslib.as_array(bare.f32_pool, shape=(bare.f32_pool_size,))
+        for i in range(full.num_bitmaps):
+            f, b = full.bitmaps[i], bare.bitmaps[i]
+            assert f.prep == 0 and (f.width, f.height) == (b.width, b.height)
+            n = f.width * f.height * 3
+            want = fpool[f.first_texel:f.first_texel + n]
+            t = bpool[b.first_texel:b.first_texel + n].copy()
+            seen.add(b.prep)
+            if b.prep & 1:
+                assert b.first_gamma_table >= 0      # the shipped textures are 8-bit BMPs
+                table = bpool[b.first_gamma_table:b.first_gamma_table + 256]
+                q = (t * np.float32(255.0) + np.float32(0.5)).astype(np.int32)
+                assert q.min() >= 0 and q.max() <= 255 and np.abs(q / 255.0 - t).max() < 1e-7
+                t = np.where(t > 0, table[q], t)
+            if b.prep & 2:
+                img = t.reshape(f.height, f.width, 3)
+                inten = ((img[..., 0] + img[..., 1]) + img[..., 2]) * (np.float32(1.0) / np.float32(3.0))
+                out = np.zeros_like(img)
+                out[..., 0] = inten - np.roll(inten, -1, axis=1)
+                out[..., 1] = inten - np.roll(inten, -1, axis=0)
+                t = out.reshape(-1)
+            assert np.array_equal(t.view(np.uint32), want.view(np.uint32)), (name, i, b.prep)
+    assert {1, 2} <= seen     # a gamma-decoded texture / cubemap and a BumpTexture were among them
