@@ -11,9 +11,11 @@
 // builder's order (pre-order child pairs, depth-first leaf lists), which makes the result deterministic and directly
 // comparable with a host-built tree.
 //
-// Scope: the work of a task is not split across workgroups, so the first levels of a mesh (few tasks, long lists) run on
-// a few CUs -- 9 rounds of 1024 triangles for the root of the 9120-triangle teapot.  For the reference's meshes the whole
-// build is a few hundred microseconds of device time plus a few microseconds of launch per level.
+// The first levels of a mesh are few tasks with long lists.  There (a task of KD_BIG triangles or more, in the first
+// KD_CHUNKED_LEVELS levels) the costly half of a task -- the two BBox::intersectTriangle tests per triangle -- is spread over the
+// whole GPU: a task's creator also lists it as chunks of KD_CHUNK triangles, kd_classify_kernel takes one chunk per workgroup and
+// leaves two bits per triangle, and the task's own workgroup then only partitions by those bits.  Same tests, same answers, same tree;
+// the root of a 120 000-triangle mesh is classified by 469 workgroups at once instead of in 118 rounds of one.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -34,11 +36,20 @@ struct KdTask {   // 64 B
 };
 
 struct KdCtl {
-	uint32_t side[2][2];   // per task-list side: {number of tasks, ints of list space claimed}
+	// per level, three sets in rotation (a level reads one, fills the next and clears the third for the level after it -- no memset between
+	// the launches): {number of tasks, ints of list space claimed, chunks listed, unused}
+	uint32_t side[3][4];
 	uint32_t node_cursor, leaf_cursor, error, max_depth;
 };
 
-struct KdCaps { uint32_t tasks, list, nodes, leaf; };
+struct KdCaps { uint32_t tasks, list, nodes, leaf, chunks; };
+
+#define KD_BIG 1024           // a task at least this long ...
+#define KD_CHUNKED_LEVELS 12  // ... and above this depth is classified chunk by chunk (kd_classify_kernel)
+#define KD_CHUNK 256
+struct KdChunk { uint32_t task, index; };   // triangles index * KD_CHUNK ... of the task's list
+
+__host__ __device__ inline bool kd_chunked(int32_t count, int32_t depth) { return count >= KD_BIG && depth < KD_CHUNKED_LEVELS; }
 
 struct P3 { double v[3]; };
 
@@ -129,13 +140,57 @@ __global__ void kd_iota_kernel(int32_t* list, uint32_t n)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) list[i] = (int32_t)i;
 }
 
+// the two halves of a task's box (BBox::split, src/bbox.h:210-216) at the midpoint of axis depth % 3 (src/mesh.cpp:100-104)
+__device__ inline void kd_halves(const KdTask& T, int& axis, double& split, BoxD& L, BoxD& R)
+{
+	axis = T.depth % 3;
+	split = T.lo[axis] + (T.hi[axis] - T.lo[axis]) * 0.5;
+	for (int c = 0; c < 3; c++) { L.lo[c] = R.lo[c] = T.lo[c]; L.hi[c] = R.hi[c] = T.hi[c]; }
+	L.hi[axis] = split;
+	R.lo[axis] = split;
+}
+
+__device__ inline uint32_t kd_sides_of(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, int tri, const BoxD& L, const BoxD& R)
+{
+	const hxr_triangle& t = tris[tri];
+	P3 A, B, C;
+	for (int k = 0; k < 3; k++) {
+		A.v[k] = verts[3 * (size_t)t.v[0] + k];
+		B.v[k] = verts[3 * (size_t)t.v[1] + k];
+		C.v[k] = verts[3 * (size_t)t.v[2] + k];
+	}
+	return (box_overlaps_triangle(L, A, B, C) ? 1u : 0u) | (box_overlaps_triangle(R, A, B, C) ? 2u : 0u);
+}
+
+// The long tasks of a level, one chunk of KD_CHUNK triangles per workgroup: which halves of the task's box each triangle touches
+// (bit 0 left, bit 1 right), stored beside the task's list entry.
+__global__ __launch_bounds__(KD_CHUNK) void kd_classify_kernel(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, const KdTask* __restrict__ tasks_in,
+                                                               int side_in, const int32_t* __restrict__ list_in, const KdChunk* __restrict__ chunks_in,
+                                                               uint8_t* __restrict__ sides, const KdCtl* __restrict__ ctl)
+{
+	const uint32_t n_chunks = ctl->side[side_in][2];
+	for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+		const KdChunk ch = chunks_in[c];
+		const KdTask T = tasks_in[ch.task];
+		const uint32_t i = ch.index * KD_CHUNK + threadIdx.x;
+		if (i >= (uint32_t)T.count) continue;
+		int axis;
+		double split;
+		BoxD L, R;
+		kd_halves(T, axis, split, L, R);
+		sides[T.first + i] = (uint8_t)kd_sides_of(tris, verts, list_in[T.first + i], L, R);
+	}
+}
+
 template <int KD_BLOCK>
 __global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* __restrict__ tris, const double* __restrict__ verts, const KdTask* __restrict__ tasks_in,
-                                                            int side_in, const int32_t* __restrict__ list_in, KdTask* __restrict__ tasks_out,
-                                                            int32_t* __restrict__ list_out, hxr_kd_node* __restrict__ nodes, int32_t* __restrict__ leaf_idx,
-                                                            KdCtl* __restrict__ ctl, int side_out, KdCaps caps)
+                                                            int side_in, const int32_t* __restrict__ list_in, const uint8_t* __restrict__ sides, KdTask* __restrict__ tasks_out,
+                                                            int32_t* __restrict__ list_out, KdChunk* __restrict__ chunks_out, hxr_kd_node* __restrict__ nodes,
+                                                            int32_t* __restrict__ leaf_idx, KdCtl* __restrict__ ctl, int side_out, KdCaps caps)
 {
 	__shared__ uint32_t s_claim[4];               // leaf: {first}; split: {list base, first child node, task slot}; [3] = 1 when a capacity ran out
+	__shared__ uint32_t s_chunk_base;
+	if (blockIdx.x == 0 && threadIdx.x < 4) ctl->side[(side_out + 1) % 3][threadIdx.x] = 0;   // the set the NEXT level fills: nobody reads or claims from it during this one
 	__shared__ uint32_t s_left[KD_BLOCK / 64], s_right[KD_BLOCK / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t n_in = ctl->side[side_in][0];   // written by the previous level (stream order): the host does not have to know it
@@ -177,12 +232,11 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* 
 		__syncthreads();
 		if (s_claim[3]) continue;
 		const uint32_t base = s_claim[0], kids = s_claim[1], slot = s_claim[2];
-		const int axis = T.depth % 3;
-		const double split = T.lo[axis] + (T.hi[axis] - T.lo[axis]) * 0.5;
+		int axis;
+		double split;
 		BoxD L, R;
-		for (int c = 0; c < 3; c++) { L.lo[c] = R.lo[c] = T.lo[c]; L.hi[c] = R.hi[c] = T.hi[c]; }   // BBox::split, src/bbox.h:210-216
-		L.hi[axis] = split;
-		R.lo[axis] = split;
+		kd_halves(T, axis, split, L, R);
+		const bool classified = kd_chunked(T.count, T.depth);   // kd_classify_kernel has been over this task's list
 		uint32_t n_left = 0, n_right = 0;
 		for (uint32_t c = 0; c < count; c += KD_BLOCK) {
 			const uint32_t i = c + tid;
@@ -190,15 +244,9 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* 
 			bool in_left = false, in_right = false;
 			if (i < count) {
 				tri = list_in[T.first + i];
-				const hxr_triangle& t = tris[tri];
-				P3 A, B, C;
-				for (int k = 0; k < 3; k++) {
-					A.v[k] = verts[3 * (size_t)t.v[0] + k];
-					B.v[k] = verts[3 * (size_t)t.v[1] + k];
-					C.v[k] = verts[3 * (size_t)t.v[2] + k];
-				}
-				in_left = box_overlaps_triangle(L, A, B, C);
-				in_right = box_overlaps_triangle(R, A, B, C);
+				const uint32_t touched = classified ? sides[T.first + i] : kd_sides_of(tris, verts, tri, L, R);
+				in_left = (touched & 1u) != 0;
+				in_right = (touched & 2u) != 0;
 			}
 			const unsigned long long bl = __ballot(in_left), br = __ballot(in_right), below = (1ull << lane) - 1;
 			if (lane == 0) { s_left[wave] = (uint32_t)__popcll(bl); s_right[wave] = (uint32_t)__popcll(br); }
@@ -228,6 +276,22 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_level_kernel(const hxr_triangle* 
 			b.node = (int32_t)kids + 1;  b.first = (int32_t)(base + count); b.count = (int32_t)n_right; b.depth = T.depth + 1;
 			tasks_out[slot] = a;
 			tasks_out[slot + 1] = b;
+			// a long child is also listed chunk by chunk for the next level's kd_classify_kernel
+			const uint32_t ch_a = kd_chunked(a.count, a.depth) ? ((uint32_t)a.count + KD_CHUNK - 1) / KD_CHUNK : 0u;
+			const uint32_t ch_b = kd_chunked(b.count, b.depth) ? ((uint32_t)b.count + KD_CHUNK - 1) / KD_CHUNK : 0u;
+			uint32_t cb = 0;
+			if (ch_a + ch_b) {
+				cb = atomicAdd(&ctl->side[side_out][2], ch_a + ch_b);
+				if (cb + ch_a + ch_b > caps.chunks) { atomicOr(&ctl->error, 1u); cb = 0xffffffffu; }
+			}
+			s_claim[0] = ch_a;
+			s_claim[1] = ch_b;
+			s_chunk_base = cb;
+		}
+		__syncthreads();
+		if (s_chunk_base != 0xffffffffu) {
+			const uint32_t ch_a = s_claim[0], ch_b = s_claim[1], cb = s_chunk_base;
+			for (uint32_t k = tid; k < ch_a + ch_b; k += KD_BLOCK) chunks_out[cb + k] = k < ch_a ? KdChunk{slot, k} : KdChunk{slot + 1, k - ch_a};
 		}
 	}
 }
@@ -291,6 +355,8 @@ struct DeviceBuffers {   // ONE allocation, sliced (a hipMalloc / hipFree pair c
 	void* block = nullptr;
 	KdTask* tasks[2] = {nullptr, nullptr};
 	int32_t* lists[2] = {nullptr, nullptr};
+	KdChunk* chunks[2] = {nullptr, nullptr};
+	uint8_t* sides = nullptr;   // kd_classify_kernel's two bits per entry of the level's input list
 	hxr_kd_node* nodes = nullptr;
 	int32_t* leaf = nullptr;
 	KdCtl* ctl = nullptr;
@@ -298,12 +364,15 @@ struct DeviceBuffers {   // ONE allocation, sliced (a hipMalloc / hipFree pair c
 	{
 		auto round = [](size_t n) { return (n + 255) & ~(size_t)255; };
 		const size_t s_tasks = round((size_t)caps.tasks * sizeof(KdTask)), s_list = round((size_t)caps.list * sizeof(int32_t)),
-		             s_nodes = round((size_t)caps.nodes * sizeof(hxr_kd_node)), s_leaf = round((size_t)caps.leaf * sizeof(int32_t)), s_ctl = round(sizeof(KdCtl));
-		const hipError_t e = hipMalloc(&block, 2 * s_tasks + 2 * s_list + s_nodes + s_leaf + s_ctl);
+		             s_nodes = round((size_t)caps.nodes * sizeof(hxr_kd_node)), s_leaf = round((size_t)caps.leaf * sizeof(int32_t)), s_ctl = round(sizeof(KdCtl)),
+		             s_chunks = round((size_t)caps.chunks * sizeof(KdChunk)), s_sides = round((size_t)caps.list);
+		const hipError_t e = hipMalloc(&block, 2 * s_tasks + 2 * s_list + 2 * s_chunks + s_sides + s_nodes + s_leaf + s_ctl);
 		if (e != hipSuccess) return e;
 		char* at = (char*)block;
 		for (int i = 0; i < 2; i++) { tasks[i] = (KdTask*)at; at += s_tasks; }
 		for (int i = 0; i < 2; i++) { lists[i] = (int32_t*)at; at += s_list; }
+		for (int i = 0; i < 2; i++) { chunks[i] = (KdChunk*)at; at += s_chunks; }
+		sides = (uint8_t*)at; at += s_sides;
 		nodes = (hxr_kd_node*)at; at += s_nodes;
 		leaf = (int32_t*)at; at += s_leaf;
 		ctl = (KdCtl*)at;
@@ -343,6 +412,13 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 	ctl.side[0][0] = 1;
 	ctl.side[0][1] = n;
 	ctl.node_cursor = 1;
+	if (kd_chunked(root.count, root.depth)) {
+		std::vector<KdChunk> root_chunks((n + KD_CHUNK - 1) / KD_CHUNK);
+		if (root_chunks.size() > caps.chunks) { *overflow = true; return 0; }
+		for (size_t k = 0; k < root_chunks.size(); k++) root_chunks[k] = KdChunk{0u, (uint32_t)k};
+		ctl.side[0][2] = (uint32_t)root_chunks.size();
+		KD_TRY(hipMemcpy(B.chunks[0], root_chunks.data(), root_chunks.size() * sizeof(KdChunk), hipMemcpyHostToDevice));
+	}
 	KD_TRY(hipMemcpy(B.tasks[0], &root, sizeof root, hipMemcpyHostToDevice));
 	KD_TRY(hipMemcpy(B.nodes, &root_node, sizeof root_node, hipMemcpyHostToDevice));
 	KD_TRY(hipMemcpy(B.ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
@@ -352,27 +428,28 @@ int attempt(const hxr_triangle* d_tris, uint32_t n, const double* d_verts, const
 	// words only every KD_LEVELS_PER_LOOK levels, to see the end of the build or a capacity overflow.  Launching a level that turns out
 	// empty costs a few microseconds, a look ~20.
 	enum { KD_LEVELS_PER_LOOK = 8, KD_GRID = 2048, KD_WIDE_LEVELS = 8 };
-	int side_in = 0, levels = 0;
+	int levels = 0;
 	bool done = false;
 	while (!done) {
 		for (int k = 0; k < KD_LEVELS_PER_LOOK; k++) {
-			const int side_out = side_in ^ 1;
-			KD_TRY(hipMemsetAsync(&B.ctl->side[side_out][0], 0, 2 * sizeof(uint32_t), nullptr));
-			// the first levels are few tasks with long lists: 1024 lanes per task there (the root of a 120 000-triangle mesh: 118 rounds
-			// instead of 469), 256 where the tasks are many and short
+			const int buf_in = levels & 1, buf_out = buf_in ^ 1;              // task / list / chunk buffers: two, swapped
+			const int set_in = levels % 3, set_out = (levels + 1) % 3;       // counter sets: three, rotated (the level clears the third itself)
+			if (levels < KD_CHUNKED_LEVELS && n >= KD_BIG)   // no task of a later level (or of a small mesh) is listed in chunks
+				hipLaunchKernelGGL(kd_classify_kernel, dim3(KD_GRID), dim3(KD_CHUNK), 0, nullptr, d_tris, d_verts, B.tasks[buf_in], set_in, B.lists[buf_in], B.chunks[buf_in],
+				                   B.sides, B.ctl);
+			// the first levels are few tasks with long lists: 1024 lanes per task there, 256 where the tasks are many and short
 			if (levels < KD_WIDE_LEVELS)
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_level_kernel<1024>), dim3(KD_GRID / 4), dim3(1024), 0, nullptr, d_tris, d_verts, B.tasks[side_in], side_in, B.lists[side_in],
-				                   B.tasks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_level_kernel<1024>), dim3(KD_GRID / 4), dim3(1024), 0, nullptr, d_tris, d_verts, B.tasks[buf_in], set_in, B.lists[buf_in], B.sides,
+				                   B.tasks[buf_out], B.lists[buf_out], B.chunks[buf_out], B.nodes, B.leaf, B.ctl, set_out, caps);
 			else
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_level_kernel<256>), dim3(KD_GRID), dim3(256), 0, nullptr, d_tris, d_verts, B.tasks[side_in], side_in, B.lists[side_in],
-				                   B.tasks[side_out], B.lists[side_out], B.nodes, B.leaf, B.ctl, side_out, caps);
-			side_in = side_out;
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_level_kernel<256>), dim3(KD_GRID), dim3(256), 0, nullptr, d_tris, d_verts, B.tasks[buf_in], set_in, B.lists[buf_in], B.sides,
+				                   B.tasks[buf_out], B.lists[buf_out], B.chunks[buf_out], B.nodes, B.leaf, B.ctl, set_out, caps);
 			levels++;
 		}
 		KD_TRY(hipGetLastError());
 		KD_TRY(hipMemcpy(&ctl, B.ctl, sizeof ctl, hipMemcpyDeviceToHost));   // the look (synchronises)
 		if (ctl.error) { *overflow = true; return 0; }
-		done = ctl.side[side_in][0] == 0;
+		done = ctl.side[levels % 3][0] == 0;
 		if (levels > KD_MAX_DEPTH + 2 * KD_LEVELS_PER_LOOK) { say(err, err_len, "kd build did not terminate"); return HXR_E_INVALID; }
 	}
 	out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -816,7 +893,7 @@ int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, cons
 	for (int tries = 0; tries < 4; tries++, scale *= 4) {
 		const uint64_t tasks = std::min<uint64_t>((4ull * n + 4096) * scale, 1ull << 27), list = std::min<uint64_t>((24ull * n + 65536) * scale, 1ull << 31),
 		               nodes = std::min<uint64_t>((8ull * n + 4096) * scale, 1ull << 28), leaf = std::min<uint64_t>((32ull * n + 65536) * scale, 1ull << 31);
-		KdCaps caps{(uint32_t)tasks, (uint32_t)(list - 1), (uint32_t)nodes, (uint32_t)(leaf - 1)};
+		KdCaps caps{(uint32_t)tasks, (uint32_t)(list - 1), (uint32_t)nodes, (uint32_t)(leaf - 1), (uint32_t)(list / (KD_CHUNK / 2) + 4096)};
 		bool overflow = false;
 		const int rc = attempt(d_tris, n, d_vertices, bbox_min, bbox_max, caps, out, &overflow, err, err_len);
 		if (rc) return rc;
