@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "hexray_hip.h"
 #define HXR_RENDER_KERNEL_ONLY
+#define HXR_TRI_DECIDE_BITWISE   // triangle_decide: the spelling these kernels are faster with (cornell16 52.2 ms against 54.2)
 #include "hxr_kernels.hip.h"
 #include "hxr_variants.h"
 
