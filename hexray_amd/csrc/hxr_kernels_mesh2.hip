@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include "hexray_hip.h"
 #define HXR_RENDER_KERNEL_ONLY
+#ifndef HXR_TRI_DECIDE_SHORT_CIRCUIT
 #define HXR_TRI_DECIDE_BITWISE   // triangle_decide: the spelling these kernels are faster with (cornell16 52.2 ms against 54.2)
+#endif
 #include "hxr_kernels.hip.h"
 #include "hxr_variants.h"
 

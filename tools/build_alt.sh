@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p build/alt_$tag
-HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -Ihexray_amd/csrc $*"
+HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude -Ihexray_amd/csrc $*"
 MESH_FLAGS=${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp}   # flags of the kd-walking translation units (override for compiler-flag A/Bs)
 hipcc $HIPFLAGS $MESH_FLAGS -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
 p1=$!

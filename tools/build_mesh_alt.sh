@@ -5,6 +5,6 @@ set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p build/alt_$tag
-hipcc --offload-arch=gfx950 -std=c++17 -fPIC -Iinclude -Ihexray_amd/csrc ${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp} "$@" -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip
+hipcc --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude -Ihexray_amd/csrc ${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp} "$@" -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip
 hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip_$tag.so build/hxr_api.o build/hxr_kd_build.o build/alt_$tag/mesh.o build/hxr_kernels_mesh2.o build/hxr_kernels_heightfield.o build/hxr_kernels_nested.o
 python3 tools/kernel_resources.py build/alt_$tag/mesh.o | grep "<false, 1u, [0-9], 1>" | cut -c1-140
