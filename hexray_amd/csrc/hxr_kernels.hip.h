@@ -605,11 +605,16 @@ HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, doub
 	        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
 	        & !(((gc < 0) != neg) & (gc != 0));   // lambda3 < 0
 #else
-	// "x * rD < 0" <=> x is non-zero and its sign differs from Dcr's <=> x with Dcr's sign bit folded in is < 0 (a zero of either
-	// sign is not): three exclusive-ors and three comparisons, no mask arithmetic in scalar registers
+	// "x * rD < 0" <=> x is non-zero and its sign differs from Dcr's <=> x times (1 with Dcr's sign) is < 0 -- an exact product, and a zero
+	// of either sign is not < 0: three multiplications and the comparisons, instead of two comparisons per numerator and mask arithmetic
+#ifdef HXR_TRI_SIGN_XOR
 	const int flip = __double2hiint(Dcr) & (int)0x80000000u;
 	const double sa = __hiloint2double(__double2hiint(ga) ^ flip, __double2loint(ga)), sb = __hiloint2double(__double2hiint(gb) ^ flip, __double2loint(gb)),
 	             sc = __hiloint2double(__double2hiint(gc) ^ flip, __double2loint(gc));
+#else
+	const double sgn = copysign(1.0, Dcr);
+	const double sa = ga * sgn, sb = gb * sgn, sc = gc * sgn;
+#endif
 	// (the two spellings compile to different mask code; each translation unit takes the one its kernels measured faster with:
 	// meshes16 7.52 -> 7.37 ms with the short-circuit form and 7.47 with the bitwise one, cornell16 53.4 -> 54.2 and 52.2)
 #ifdef HXR_TRI_DECIDE_BITWISE

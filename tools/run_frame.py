@@ -9,7 +9,9 @@ frames = int(sys.argv[2] or 3)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 scene_name, ov, desc = bench.WORKLOADS[wl]
-hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+if os.environ.get("HXR_OV"):   # e.g. HXR_OV="width=960,height=540,num_samples=64": override entries of the workload's overlay
+    ov = dict(ov, **{k: int(v) for k, v in (kv.split("=") for kv in os.environ["HXR_OV"].split(","))})
+hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov, extra=os.environ.get("HXR_EXTRA_OVERLAY", "")))   # HXR_EXTRA_OVERLAY: more scene text for experiments
 hx.init(0)
 ds = hx.DeviceScene(hs, accel=hx.ACCEL_SAH if os.environ.get('HXR_ACCEL') == 'sah' else hx.ACCEL_REFERENCE)
 p = hx.frame_params(tile_size=32)
