@@ -65,7 +65,9 @@ enum : unsigned {
 	// a refracted ray, 2.4 GB of scratch writes per frame before this).
 	HXR_F_LDSSTACK = 4096u
 };
-#define HXR_LDS_RAY_SLOTS 4   // 4 x 18 dwords x 256 lanes = 72 KB per block: two blocks per CU (2 waves per SIMD) fit the 160 KB
+#ifndef HXR_LDS_RAY_SLOTS
+#define HXR_LDS_RAY_SLOTS 2   // 2 x 18 dwords x 256 lanes = 36 KB per block: three blocks per CU (3 waves per SIMD) fit the 160 KB; 4 slots (72 KB) allow two
+#endif
 
 // counters (COUNT builds only); order = hxr_counters
 enum {
@@ -1009,7 +1011,11 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 		if (marching && !need_tri) {
 			x0 = (int)floor(p.x);
 			z0 = (int)floor(p.z);
+#ifdef HXR_HF_BRANCHY
 			if (x0 < 0 || x0 >= F.W || z0 < 0 || z0 >= F.H) {
+#else
+			if (((unsigned)x0 >= (unsigned)F.W) | ((unsigned)z0 >= (unsigned)F.H)) {   // one comparison per coordinate, no nested masks
+#endif
 				marching = false;
 			} else {
 				const size_t cell = (size_t)z0 * F.W + x0;   // (x0, z0) is in range here: no clamping needed
@@ -1053,6 +1059,7 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 					tl.add(HC_HFHIGH, k < F.max_k ? k : F.max_k - 1);   // probes made: every passed level plus the failed one
 					k--;
 				}
+#ifdef HXR_HF_BRANCHY
 				if (k > 0) {
 					p = p + step * (double)(1 << k);
 					marching = box_holds(box, p);
@@ -1068,6 +1075,20 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 						marching = box_holds(box, p);
 					}
 				}
+#else
+				// the skip of 2^k cells and the step to the next cell border are the same statement with another length: formed once, for
+				// lanes of both kinds (a wave usually holds both, and then ran both branches)
+				const double lx = d.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
+				const double lz = d.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
+				const double len = k > 0 ? (double)(1 << k) : fmin(lx, lz) + 1e-6;
+				pn = p + step * len;
+				if (k == 0) tl.add(HC_HFHEIGHT);
+				need_tri = k == 0 && fmin(p.y, pn.y) < cell_max;
+				if (!need_tri) {
+					p = pn;
+					marching = box_holds(box, p);
+				}
+#endif
 			}
 		}
 		const uint64_t waiting = hxr_ballot(need_tri);

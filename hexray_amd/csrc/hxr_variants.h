@@ -57,7 +57,9 @@
 	X(true, ((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST), 2)
 // hxr_kernels_heightfield.hip
 #ifndef HXR_HEIGHTFIELD_WAVES
-#define HXR_HEIGHTFIELD_WAVES 2   // waves per SIMD of the heightfield kernels (heightfield16: 9.14 ms at 2, 11.2 at 3) and, below, of the sphere path tracer; re-measured at the end of round 2
+#define HXR_HEIGHTFIELD_WAVES 3   // waves per SIMD of the heightfield kernels.  Round 3: 3 waves with TWO ray-stack entries in LDS (HXR_LDS_RAY_SLOTS; four allow two waves only)
+                                  // and the unit compiled -O1 (build.sh): heightfield16 8.65 -> 7.77 ms; -O2 spills the same 168 registers differently and takes 9.04;
+                                  // 4 waves 8.50; round 2 had 9.14 ms at 2 waves, 11.2 at 3
 #endif
 #ifndef HXR_SPHERE_GI_WAVES
 #define HXR_SPHERE_GI_WAVES 3   // smallpt 16 paths: 37.2 ms at 2, 31.4 at 3, 32.3 at 4 (round 1, before the turns: 2 was 21 % ahead of 3)

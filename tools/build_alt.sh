@@ -9,7 +9,7 @@ HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude -I
 MESH_FLAGS=${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp}   # flags of the kd-walking translation units (override for compiler-flag A/Bs)
 hipcc $HIPFLAGS $MESH_FLAGS -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
 p1=$!
-hipcc $HIPFLAGS ${HF_FLAGS:--O2} -c -o build/alt_$tag/hf.o hexray_amd/csrc/hxr_kernels_heightfield.hip &
+hipcc $HIPFLAGS ${HF_FLAGS:--O1} -c -o build/alt_$tag/hf.o hexray_amd/csrc/hxr_kernels_heightfield.hip &
 p2=$!
 hipcc $HIPFLAGS $MESH_FLAGS -c -o build/alt_$tag/mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
 p3=$!
