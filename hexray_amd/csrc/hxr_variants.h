@@ -74,6 +74,9 @@
 #define HXR_INSTANTIATE(C, F, W)                                                    \
 	template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
 	template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
+// one render mode only: M = 1 (Monte-Carlo, known at compile time) / M = -1 (taken from HxrLaunch::mode)
+#define HXR_INSTANTIATE_MONTE_CARLO(C, F, W) template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);
+#define HXR_INSTANTIATE_LAUNCH_MODE(C, F, W) template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
 #define HXR_DECLARE_EXTERN(C, F, W)                                                        \
 	extern template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
 	extern template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
