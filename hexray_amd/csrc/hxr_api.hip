@@ -20,7 +20,8 @@
 #include "hxr_variants.h"
 // compiled in hxr_kernels_mesh.hip / hxr_kernels_mesh2.hip / hxr_kernels_heightfield.hip with their own flags
 HXR_VARIANTS_MESH_DEFER(HXR_DECLARE_EXTERN)
-HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_LAUNCH_MODE)
+HXR_VARIANTS_MESH_INPLACE_MC(HXR_DECLARE_EXTERN_MONTE_CARLO)
 HXR_VARIANTS_MESH_STACK1(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_CONTINUE)
 HXR_VARIANTS_MESH_LANEWALK(HXR_DECLARE_EXTERN_CONTINUE)
@@ -502,6 +503,23 @@ Variant pick_variant(const hxr_scene* s)
 	return three ? V_ALL_3 : V_ALL_2;
 }
 
+// Waves of the render kernel a CU holds at once (4 SIMDs x the occupancy the variant is compiled for): what the schedule takes for "a wave's even
+// share of the frame" (hxr_sched_build_kernel).  A wrong figure here makes the split threshold swing from frame to frame: the 4-waves build of
+// the headline kernel ran 6.76 ... 7.77 ms with the 12 that used to be written here, and 6.84 with its own 16.
+int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place)
+{
+	if (const char* e = getenv("HXR_SCHED_RESIDENT")) return std::max(1, atoi(e));   // developer aid
+	switch (pick_variant(s)) {
+		case V_MESH: return 4 * (!in_place ? 3 : (mode == 1 ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES));
+		case V_MESH_REFRACT: return 4 * (!in_place ? 3 : HXR_MESH_WAVES);
+		case V_HEIGHTFIELD: return 4 * HXR_HEIGHTFIELD_WAVES;
+		case V_SPHERE_GI: return 4 * HXR_SPHERE_GI_WAVES;
+		case V_MESH_GI: return 4 * HXR_MESH_GI_WAVES;
+		case V_NESTED: case V_NESTED_GI: case V_ALL_2: case V_ALL_GI_2: return 8;
+		default: return 12;
+	}
+}
+
 // Deferred secondary rays: does this launch use them, and with what queue?  Only the Whitted mesh variants have a deferring
 // build; the queue is sized for the worst case (every lane of every packet of a dispenser range emits `fanout0` rays), so an
 // append can never fail, and a frame whose worst case does not fit HXR_QUEUE_MAX_RECORDS is traced in place as before.
@@ -564,6 +582,12 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		if (L.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);     \
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, -1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);                \
 	} while (0)
+// ... for a variant whose Monte-Carlo instance is compiled for another occupancy than the instance that takes its mode from the launch
+#define HXR_LAUNCH_W2(CNT, FEAT, WAVES_MC, WAVES)                                                                                                         \
+	do {                                                                                                                                                      \
+		if (L.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES_MC, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);  \
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, -1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);                \
+	} while (0)
 #define HXR_LAUNCH_F(FEAT, WAVES)                                                         \
 	do {                                                                                  \
 		if (counters) HXR_LAUNCH(true, FEAT, WAVES); else HXR_LAUNCH(false, FEAT, WAVES); \
@@ -583,7 +607,8 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 			case V_MESH:
 				if (defer) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_DEFER, HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
 				else if (one_pending) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_STACK1, HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
-				else HXR_LAUNCH_F2(HXR_F_MESH, HXR_F_MESH | HXR_F_REFRACT, HXR_MESH_WAVES);
+				else if (counters) HXR_LAUNCH(true, HXR_F_MESH | HXR_F_REFRACT, HXR_MESH_WAVES);
+				else HXR_LAUNCH_W2(false, HXR_F_MESH, HXR_MESH_MC_WAVES, HXR_MESH_WAVES);
 				break;
 			case V_MESH_REFRACT:
 				if (defer) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
@@ -601,6 +626,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 			case V_NESTED: HXR_LAUNCH_F((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST, 2); break;
 		}
 #undef HXR_LAUNCH_F2
+#undef HXR_LAUNCH_W2
 #undef HXR_LAUNCH_F
 #undef HXR_LAUNCH
 		HIP_TRY(hipGetLastError());
@@ -701,7 +727,7 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		if (const char* e = getenv("HXR_SCHED_FRAME_DIV")) frame_div = (uint32_t)atoi(e);
 		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
-		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * 12u, frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
+		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, defer_capacity(s, L.num_chunks, L.spp) == 0 && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr)), frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
 		HIP_TRY(hipGetLastError());
 	} else {

@@ -9,4 +9,4 @@
 #include "hxr_kernels.hip.h"
 #include "hxr_variants.h"
 
-HXR_VARIANTS_MESH_INPLACE(HXR_INSTANTIATE_MONTE_CARLO)
+HXR_VARIANTS_MESH_INPLACE_MC(HXR_INSTANTIATE_MONTE_CARLO)

@@ -24,6 +24,17 @@
 	X(false, (HXR_F_MESH), HXR_MESH_WAVES)                 \
 	X(false, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES) \
 	X(true, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES)
+// ... whose Monte-Carlo instances (render mode known at compile time) live in hxr_kernels_mesh_mc.hip, the one without refraction -- the headline
+// kernel -- compiled for FOUR waves per SIMD: 6.86 ms against 7.12 at three (the SAH frame 5.79 against 6.00) once the schedule is told the right number of
+// resident waves (resident_waves_per_cu, hxr_api.hip).  The instances whose mode arrives at launch (adaptive anti-aliasing, prepass, interactive)
+// lose 10 % at four waves and stay at HXR_MESH_WAVES.
+#ifndef HXR_MESH_MC_WAVES
+#define HXR_MESH_MC_WAVES 4
+#endif
+#define HXR_VARIANTS_MESH_INPLACE_MC(X)          \
+	X(false, (HXR_F_MESH), HXR_MESH_MC_WAVES)              \
+	X(false, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES) \
+	X(true, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES)
 // ... with at most one secondary ray pending per lane (no Layered shader of the scene has two Reflection / Refraction layers): the
 // default for mesh scenes -- the per-lane ray stack leaves scratch memory
 #define HXR_VARIANTS_MESH_STACK1(X)                              \
@@ -81,4 +92,6 @@
 	extern template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);      \
 	extern template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
 #define HXR_INSTANTIATE_CONTINUE(C, F, W) template __global__ void hxr_continue_kernel<C, F, W>(HXR_KERNEL_PARAMS);
+#define HXR_DECLARE_EXTERN_MONTE_CARLO(C, F, W) extern template __global__ void hxr_render_kernel<C, F, W, 1>(HXR_KERNEL_PARAMS);
+#define HXR_DECLARE_EXTERN_LAUNCH_MODE(C, F, W) extern template __global__ void hxr_render_kernel<C, F, W, -1>(HXR_KERNEL_PARAMS);
 #define HXR_DECLARE_EXTERN_CONTINUE(C, F, W) extern template __global__ void hxr_continue_kernel<C, F, W>(HXR_KERNEL_PARAMS);
