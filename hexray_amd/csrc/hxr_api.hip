@@ -714,6 +714,13 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	HIP_TRY(hipMemsetAsync(s->d_sched_part, 0, (size_t)HXR_PART_SLOTS * sizeof(uint32_t), st));
 	if (!s->d_sched_ctl) HIP_TRY(hipMalloc((void**)&s->d_sched_ctl, 64));
 	const hxr_scene::SchedKey key = {p.W, p.H, p.mode, p.spp, p.tile, p.rank, p.count, n};
+	if (getenv("HXR_SCHED_VERBOSE") && s->sched_history) {   // developer aid: what the LAST frame's schedule listed (synchronises)
+		unsigned long long ctl[8] = {0};
+		if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(ctl, s->d_sched_ctl, sizeof ctl, hipMemcpyDeviceToHost) == hipSuccess) {
+			const uint32_t* w = (const uint32_t*)ctl;
+			fprintf(stderr, "[hxr] last schedule: total cost %llu, listed pixels / parts %u, whole chunks first %u, part slots %u\n", ctl[0], w[2], w[3], w[4]);
+		}
+	}
 	const bool usable = s->sched_history && memcmp(&key, &s->sched_key, sizeof key) == 0;
 	HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
 	if (usable) {

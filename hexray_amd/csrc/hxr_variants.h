@@ -50,7 +50,7 @@
 	X(false, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)     \
 	X(true, (HXR_F_MESH | HXR_F_REFRACT | HXR_F_LANEWALK), HXR_LANEWALK_WAVES)
 #ifndef HXR_MESH_GI_WAVES
-#define HXR_MESH_GI_WAVES 3
+#define HXR_MESH_GI_WAVES 4   // cornell16 (round 3, with the schedule told the real occupancy): 50.3 ms at 3, 48.3 at 4 (-O2; 48.5 at -O1)
 #endif
 // hxr_kernels_mesh2.hip: path tracing over meshes and the catch-alls for scenes with meshes
 #define HXR_VARIANTS_MESH_OTHER(X)                                      \
@@ -73,7 +73,7 @@
                                   // 4 waves 8.50; round 2 had 9.14 ms at 2 waves, 11.2 at 3
 #endif
 #ifndef HXR_SPHERE_GI_WAVES
-#define HXR_SPHERE_GI_WAVES 3   // smallpt 16 paths: 37.2 ms at 2, 31.4 at 3, 32.3 at 4 (round 1, before the turns: 2 was 21 % ahead of 3)
+#define HXR_SPHERE_GI_WAVES 4   // smallpt 16 paths, round 3: 29.2 ms at 3, 27.3 at 4 (-O3; 28.0 at -O1) -- round 1 had 31.4 at 3 and 32.3 at 4 with the schedule assuming 12 resident waves per CU
 #endif
 #ifndef HXR_HEIGHTFIELD_F
 #define HXR_HEIGHTFIELD_F (HXR_F_HEIGHTFIELD | HXR_F_REFRACT | HXR_F_LDSSTACK)   // the first entries of the per-lane ray stack in LDS (round 3)
