@@ -516,6 +516,7 @@ int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place)
 		case V_SPHERE_GI: return 4 * HXR_SPHERE_GI_WAVES;
 		case V_MESH_GI: return 4 * HXR_MESH_GI_WAVES;
 		case V_NESTED: case V_NESTED_GI: case V_ALL_2: case V_ALL_GI_2: return 8;
+		case V_ALL_3: return 4 * HXR_ALL_WHITTED_WAVES;
 		default: return 12;
 	}
 }
@@ -620,7 +621,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 			case V_MESH_GI: HXR_LAUNCH_F(HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT, HXR_MESH_GI_WAVES); break;
 			case V_ALL_GI_3: HXR_LAUNCH_F(HXR_F_ALL, 3); break;
 			case V_ALL_GI_2: HXR_LAUNCH_F(HXR_F_ALL, 2); break;
-			case V_ALL_3: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 3); break;
+			case V_ALL_3: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, HXR_ALL_WHITTED_WAVES); break;
 			case V_ALL_2: HXR_LAUNCH_F(HXR_F_ALL & ~HXR_F_GI, 2); break;
 			case V_NESTED_GI: HXR_LAUNCH_F(HXR_F_ALL | HXR_F_CSGNEST, 2); break;
 			case V_NESTED: HXR_LAUNCH_F((HXR_F_ALL & ~HXR_F_GI) | HXR_F_CSGNEST, 2); break;

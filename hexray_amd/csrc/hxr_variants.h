@@ -52,14 +52,17 @@
 #ifndef HXR_MESH_GI_WAVES
 #define HXR_MESH_GI_WAVES 4   // cornell16 (round 3, with the schedule told the real occupancy): 50.3 ms at 3, 48.3 at 4 (-O2; 48.5 at -O1)
 #endif
+#ifndef HXR_ALL_WHITTED_WAVES
+#define HXR_ALL_WHITTED_WAVES 3   // the Whitted catch-all (kdtree_test, simple, boxed, bokeh ...)
+#endif
 // hxr_kernels_mesh2.hip: path tracing over meshes and the catch-alls for scenes with meshes
 #define HXR_VARIANTS_MESH_OTHER(X)                                      \
 	X(false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)   \
 	X(true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)    \
 	X(false, (HXR_F_ALL), 3)                                            \
 	X(true, (HXR_F_ALL), 3)                                             \
-	X(false, (HXR_F_ALL & ~HXR_F_GI), 3)                                \
-	X(true, (HXR_F_ALL & ~HXR_F_GI), 3)
+	X(false, (HXR_F_ALL & ~HXR_F_GI), HXR_ALL_WHITTED_WAVES)            \
+	X(true, (HXR_F_ALL & ~HXR_F_GI), HXR_ALL_WHITTED_WAVES)
 // hxr_kernels_nested.hip: the catch-alls for scenes whose CSG operations have operations as operands (HXR_F_CSGNEST)
 #define HXR_VARIANTS_NESTED_CSG(X)                              \
 	X(false, (HXR_F_ALL | HXR_F_CSGNEST), 2)                    \
