@@ -506,11 +506,20 @@ Variant pick_variant(const hxr_scene* s)
 // Waves of the render kernel a CU holds at once (4 SIMDs x the occupancy the variant is compiled for): what the schedule takes for "a wave's even
 // share of the frame" (hxr_sched_build_kernel).  A wrong figure here makes the split threshold swing from frame to frame: the 4-waves build of
 // the headline kernel ran 6.76 ... 7.77 ms with the 12 that used to be written here, and 6.84 with its own 16.
-int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place)
+// The in-place Monte-Carlo mesh kernel exists at 4 and at 3 waves per SIMD (hxr_variants.h): four when every resident wave has a long queue of
+// packets (throughput), three when the launch is a few packets deep (one packet's latency): 2-way shards of the headline frame gain 6 % from the
+// fourth wave, 4-way shards nothing, 8-way shards lose 12 %.
+int mesh_mc_waves(const hxr_scene* s, uint32_t num_chunks)
+{
+	if (const char* e = getenv("HXR_MESH_MC_FOUR")) return atoi(e) ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES;   // developer aid
+	return num_chunks >= (uint32_t)s->num_cu * 4u * HXR_MESH_MC_WAVES * 24u ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES;
+}
+
+int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place, uint32_t num_chunks)
 {
 	if (const char* e = getenv("HXR_SCHED_RESIDENT")) return std::max(1, atoi(e));   // developer aid
 	switch (pick_variant(s)) {
-		case V_MESH: return 4 * (!in_place ? 3 : (mode == 1 ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES));
+		case V_MESH: return 4 * (!in_place ? 3 : (mode == 1 ? mesh_mc_waves(s, num_chunks) : HXR_MESH_WAVES));
 		case V_MESH_REFRACT: return 4 * (!in_place ? 3 : HXR_MESH_WAVES);
 		case V_HEIGHTFIELD: return 4 * HXR_HEIGHTFIELD_WAVES;
 		case V_SPHERE_GI: return 4 * HXR_SPHERE_GI_WAVES;
@@ -609,7 +618,8 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 				if (defer) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_DEFER, HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
 				else if (one_pending) HXR_LAUNCH_F2(HXR_F_MESH | HXR_F_STACK1, HXR_F_MESH | HXR_F_REFRACT | HXR_F_STACK1, 3);
 				else if (counters) HXR_LAUNCH(true, HXR_F_MESH | HXR_F_REFRACT, HXR_MESH_WAVES);
-				else HXR_LAUNCH_W2(false, HXR_F_MESH, HXR_MESH_MC_WAVES, HXR_MESH_WAVES);
+				else if (mesh_mc_waves(s, L.num_chunks) == HXR_MESH_MC_WAVES) HXR_LAUNCH_W2(false, HXR_F_MESH, HXR_MESH_MC_WAVES, HXR_MESH_WAVES);
+				else HXR_LAUNCH(false, HXR_F_MESH, HXR_MESH_WAVES);
 				break;
 			case V_MESH_REFRACT:
 				if (defer) HXR_LAUNCH_F(HXR_F_MESH | HXR_F_REFRACT | HXR_F_DEFER, 3);
@@ -735,7 +745,7 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		if (const char* e = getenv("HXR_SCHED_FRAME_DIV")) frame_div = (uint32_t)atoi(e);
 		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
-		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, defer_capacity(s, L.num_chunks, L.spp) == 0 && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr)), frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
+		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, defer_capacity(s, L.num_chunks, L.spp) == 0 && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr), n), frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
 		HIP_TRY(hipGetLastError());
 	} else {
