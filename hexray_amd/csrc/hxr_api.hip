@@ -26,6 +26,7 @@ HXR_VARIANTS_MESH_STACK1(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_CONTINUE)
 HXR_VARIANTS_MESH_LANEWALK(HXR_DECLARE_EXTERN_CONTINUE)
 HXR_VARIANTS_MESH_OTHER(HXR_DECLARE_EXTERN)
+HXR_VARIANTS_MESH_GI(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_HEIGHTFIELD(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_NESTED_CSG(HXR_DECLARE_EXTERN)
 

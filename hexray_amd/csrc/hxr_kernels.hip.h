@@ -1917,6 +1917,9 @@ HXR_DEV float* out_pixel(const HxrLaunch& P, uint32_t q, int x, int y)
 #ifndef HXR_BLOCK
 #define HXR_BLOCK 256
 #endif
+#ifndef HXR_SCHED_URGENT_DIV
+#define HXR_SCHED_URGENT_DIV 8u   // a whole chunk costing more than 1/8 of a wave's even share of the frame starts in the first round
+#endif
 #define HXR_SCHED_WHOLE 0x80000000u   // schedule item flag: the whole chunk that starts at this pixel
 #define HXR_SCHED_PART 0x40000000u    // schedule item flag: bits 22..29 = which HXR_PART_LANES samples, bits 0..21 = part slot
 #define HXR_SCHED_QUARTER 0x20000000u // schedule item flag (not a PART): the HXR_QUARTER_LANES pixels that start at this pixel (1-spp packets only)
@@ -2392,6 +2395,11 @@ __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc,
 			} else if (c > split_above && ppc > 1) {
 				const uint32_t at = atomicAdd(counts + 0, cnt);
 				for (uint32_t j = 0; j < cnt; j++) items[at + j] = first + j;
+			} else if (c > split_above / HXR_SCHED_URGENT_DIV) {
+				// long against the frame, though not long enough to split: at the FRONT, behind the split ones -- the back list is thousands
+				// of chunks in the order their atomics landed, two rounds of the resident waves deep, and a packet of a millisecond that
+				// happens to sit in its second half ends the frame late (one frame in six, at four waves per SIMD)
+				items[atomicAdd(counts + 0, 1u)] = first | HXR_SCHED_WHOLE;
 			} else {
 				const uint32_t at = atomicAdd(counts + 1, 1u);
 				items[capacity - 1u - at] = first | HXR_SCHED_WHOLE;

@@ -1,5 +1,5 @@
-// Path tracing over meshes and the catch-all variants for scenes with meshes: same flags as hxr_kernels_mesh.hip (cornell box
-// 66.5 -> 65.5 ms under max-ilp), a unit of their own so that the two compile side by side.
+// The catch-all variants for scenes with meshes (path tracing over meshes alone: hxr_kernels_mesh_gi.hip), a unit of their own so that the
+// units compile side by side; -O2 with the max-ilp scheduling strategy (build.sh).
 #include <hip/hip_runtime.h>
 #include "hexray_hip.h"
 #define HXR_RENDER_KERNEL_ONLY

@@ -58,10 +58,12 @@
 #ifndef HXR_ALL_WHITTED_WAVES
 #define HXR_ALL_WHITTED_WAVES 3   // the Whitted catch-all (kdtree_test, simple, boxed, bokeh ...)
 #endif
-// hxr_kernels_mesh2.hip: path tracing over meshes and the catch-alls for scenes with meshes
-#define HXR_VARIANTS_MESH_OTHER(X)                                      \
+// hxr_kernels_mesh_gi.hip: path tracing over meshes
+#define HXR_VARIANTS_MESH_GI(X)                                      \
 	X(false, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)   \
-	X(true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)    \
+	X(true, (HXR_F_MESH | HXR_F_GI | HXR_F_RECT | HXR_F_REFRACT), HXR_MESH_GI_WAVES)
+// hxr_kernels_mesh2.hip: the catch-alls for scenes with meshes
+#define HXR_VARIANTS_MESH_OTHER(X)                                      \
 	X(false, (HXR_F_ALL), 3)                                            \
 	X(true, (HXR_F_ALL), 3)                                             \
 	X(false, (HXR_F_ALL & ~HXR_F_GI), HXR_ALL_WHITTED_WAVES)            \
