@@ -338,6 +338,25 @@ def test_adaptive_schedule_does_not_change_the_frame(gpu):
             assert c[k] == oc[k], (k, c[k], oc[k])
 
 
+def test_the_two_occupancies_of_the_monte_carlo_mesh_kernel_render_the_same_frame(gpu, monkeypatch):
+    """The in-place Monte-Carlo mesh kernel is compiled for four and for three waves per SIMD, and the module takes one or the other by the
+    launch's work per resident wave (mesh_mc_waves, hxr_api.hip).  Same source, other register budget: the frames -- first and scheduled --
+    must be the same bits, whichever is forced, and a 4-way shard's tiles the tiles of the whole frame."""
+    hs = hx.HostScene(scene_path("meshes.hexray"), hx.overlay_text(640, 360, dof=True, num_samples=16))
+    frames = {}
+    for forced in ("1", "0"):
+        monkeypatch.setenv("HXR_MESH_MC_FOUR", forced)
+        ds = hx.DeviceScene(hs)
+        frames[forced] = [ds.render(hx.frame_params()) for _ in range(3)]
+    monkeypatch.delenv("HXR_MESH_MC_FOUR")
+    picked = hx.DeviceScene(hs).render(hx.frame_params())
+    for f in frames["1"] + frames["0"]:
+        assert np.array_equal(f, picked)
+    o, _ = oracle_render(hs, hx.frame_params())
+    rms = np.sqrt(np.mean((picked.astype(np.float64) - o) ** 2, axis=(0, 1)))
+    assert rms.max() <= 1e-4, rms
+
+
 STEREO = [
     ("meshes.hexray", hx.overlay_text(160, 120, want_aa=False, extra="Camera {\nstereoSeparation 0.3\n}\n"), dict(mode=hx.MODE_SINGLE)),
     ("meshes.hexray", hx.overlay_text(96, 72, dof=True, num_samples=4, extra="Camera {\nstereoSeparation 0.3\n}\n"), dict()),
