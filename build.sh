@@ -32,7 +32,8 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	NESTED_TU_FLAGS="-O2"
 	# NOT max-memory-clause for these two, although it measured faster (kdtree_test 9.73 -> 9.23 ms, smallpt16 27.3 -> 26.7): the Whitted catch-all
 	# built that way raised a GPU memory fault on the first frame of one generated scene (tests/test_gpu_fuzz.py, seed 24: anaglyph camera + CSG + mesh)
-	# that the max-ilp build renders correctly -- cause not found, so the strategy stays where the whole GPU suite has passed with it
+	# that the max-ilp build renders correctly (with ONLY the API unit built that way the same tests pass: it is the catch-all kernel -- the largest of all,
+	# two inlined copies of the integrator for the anaglyph pair).  Cause not found, so both units keep the flags the whole GPU suite has passed with
 	MESH2_TU_FLAGS="-O2 -mllvm -amdgpu-sched-strategy=max-ilp"
 	API_TU_FLAGS="-O3"
 	# stale objects must not survive a failed recompile (a bare `wait` returns 0 whatever the jobs did)
