@@ -30,12 +30,13 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	MESH_MC_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-memory-clause"   # the headline kernel (hxr_kernels_mesh_mc.hip): 6.57 ms, against 6.78 with max-ilp and 7.25 at -O2
 	HF_TU_FLAGS="-O1"    # the heightfield marcher at 3 waves per SIMD: -O1 keeps its spills out of the marching loop (7.77 ms against 9.04 at -O2)
 	NESTED_TU_FLAGS="-O2"
-	# NOT max-memory-clause for these two, although it measured faster (kdtree_test 9.73 -> 9.23 ms, smallpt16 27.3 -> 26.7): the Whitted catch-all
+	# NOT max-memory-clause for the catch-all unit, although it measured faster (kdtree_test 9.73 -> 9.23 ms): the Whitted catch-all
 	# built that way raised a GPU memory fault on the first frame of one generated scene (tests/test_gpu_fuzz.py, seed 24: anaglyph camera + CSG + mesh)
 	# that the max-ilp build renders correctly (with ONLY the API unit built that way the same tests pass: it is the catch-all kernel -- the largest of all,
-	# two inlined copies of the integrator for the anaglyph pair).  Cause not found, so both units keep the flags the whole GPU suite has passed with
+	# two inlined copies of the integrator for the anaglyph pair).  Cause not found, so that unit keeps the flags the whole GPU suite has passed with
 	MESH2_TU_FLAGS="-O2 -mllvm -amdgpu-sched-strategy=max-ilp"
-	API_TU_FLAGS="-O3"
+	MESH_GI_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-memory-clause"   # cornell16 48.2 -> 47.2 ms
+	API_TU_FLAGS="-O3 -mllvm -amdgpu-sched-strategy=max-memory-clause"        # holds the sphere path tracer: smallpt16 27.3 -> 26.7 ms
 	# stale objects must not survive a failed recompile (a bare `wait` returns 0 whatever the jobs did)
 	rm -f build/hxr_kernels_mesh.o build/hxr_kernels_mesh_gi.o build/hxr_kernels_mesh_mc.o build/hxr_kernels_mesh2.o build/hxr_kernels_heightfield.o build/hxr_api.o build/hxr_kd_build.o build/hxr_kernels_nested.o
 	hipcc $HIPFLAGS $MESH_TU_FLAGS -c -o build/hxr_kernels_mesh.o hexray_amd/csrc/hxr_kernels_mesh.hip &
@@ -44,7 +45,7 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	p2=$!
 	hipcc $HIPFLAGS $MESH2_TU_FLAGS -c -o build/hxr_kernels_mesh2.o hexray_amd/csrc/hxr_kernels_mesh2.hip &
 	p3=$!
-	hipcc $HIPFLAGS $MESH_TU_FLAGS -c -o build/hxr_kernels_mesh_gi.o hexray_amd/csrc/hxr_kernels_mesh_gi.hip &
+	hipcc $HIPFLAGS $MESH_GI_TU_FLAGS -c -o build/hxr_kernels_mesh_gi.o hexray_amd/csrc/hxr_kernels_mesh_gi.hip &
 	p6=$!
 	hipcc $HIPFLAGS $NESTED_TU_FLAGS -c -o build/hxr_kernels_nested.o hexray_amd/csrc/hxr_kernels_nested.hip &
 	p4=$!
