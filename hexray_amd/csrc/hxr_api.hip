@@ -739,7 +739,7 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		const int grid = (int)std::min<uint32_t>((n + 255u) / 256u, 1024u);
 		const int sum_grid = (int)std::min<uint32_t>((n + 255u) / 256u, 64u);   // one 64-bit atomic per wave on ONE word: 4096 of them cost 50 us, 256 cost 3
 		// thresholds in multiples of the mean chunk cost: split into one-pixel packets / start first as a whole
-		uint32_t split_x = 16, first_x = 8;
+		uint32_t split_x = 16, first_x = 6;   // first_x re-measured in round 3 at four waves per SIMD: 6.74 ms at 1, 6.69 at 2, 6.56 at 3, 6.51 at 4 and 6, 6.56 at 8, 6.73 at 16
 		if (const char* e = getenv("HXR_SCHED_SPLIT_X")) split_x = (uint32_t)atoi(e);   // developer aids
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
 		uint32_t frame_div = 1;   // "long against the frame": more than 1/frame_div of a wave's even share of the work (1 beat 2 and 4 at every N)
