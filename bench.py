@@ -10,10 +10,15 @@ torch.distributed.run, one rank per GPU) the frame's 32x32 tiles are dealt round
 rank renders its tiles, and ONE RCCL gather brings them to rank 0, which assembles the frame: the total
 work per step is fixed, so scaling is "strong".
 
-Rank 0 prints one JSON line.  `roofline.achieved` is algorithmic bytes per launch (SURVEY.md section 8d
-formula over the frame's own work counters) divided by the render kernel's mean duration measured with HIP
-events on the launch stream; `cpu_baseline` times the CPU oracle (test infrastructure, a port of the
-reference's algorithm) on this host's cores for the same frame, N = 1 only.
+Rank 0 prints one JSON line.  `roofline` is the one that binds this kernel -- FP64 vector-ALU issue (SURVEY.md section 8d names it as
+the secondary roofline; the working set lives in L2 / Infinity Cache, so the HBM line of 8d does not bind): `achieved` = useful FP64
+flop per launch (FMA / MUL / ADD wave-instructions x 64 lanes x the measured VALU lane utilisation) / the render kernel's mean
+duration from HIP events on the launch stream, `peak` = 78.6 TFLOP/s, so `frac` <= 1 by construction.  The counters behind it
+(and `traffic`, the HBM bytes per launch) are collected BY THIS RUN: three `rocprofv3 --pmc` child processes (counters only, one
+pass each for the SQ set, FETCH_SIZE and WRITE_SIZE) render the same workload before this process touches the GPU.  Where that is not
+possible the committed profile is used, labelled, and only when it was taken on the kernel sources of this checkout (`kernel_build`).
+SURVEY.md 8d's algorithmic-bytes figure stays beside it as `hbm_algorithmic`.  `cpu_baseline` times the CPU oracle (test
+infrastructure, a port of the reference's algorithm) on this host's cores for the same frame, N = 1 only.
 
 What `value` is and is not: the timed frames are steady-state re-renders of the same frame into a device buffer -- from the
 second frame on the packet schedule is seeded by the previous frame's per-packet clocks.  `other_timings`
@@ -52,6 +57,16 @@ WORKLOADS = {
 TILE = 64          # single GPU: only the order of the packets depends on it (the reference's bucket size; tools/tile_sweep.py: 8.80-8.85 ms at 64 / 128 / 8, 8.92 at 32)
 SHARD_TILE = 8     # N > 1: tiles are dealt round-robin to the ranks; 8x8 spreads the expensive image regions best (rank time max/mean 1.13 vs 1.35 at 32)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 FP64 FMA lanes x 2 flop x 2.4 GHz
+# rocprofv3 --pmc passes of the live counter collection (MI355X_MICROARCH.md, "rocprofv3 PMC slots": 8 SQ + 2 GRBM per pass; FETCH_SIZE and
+# WRITE_SIZE do not fit one pass).  Counters only: no tracing domain is combined with --pmc.
+PMC_PASSES = (
+    ("sq", ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+            "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "GRBM_GUI_ACTIVE")),
+    ("fetch", ("FETCH_SIZE",)),
+    ("write", ("WRITE_SIZE",)),
+)
+PMC_CHILD_FRAMES = 4    # frames a counter pass renders; the LAST dispatch of the render kernel is read (steady state: scheduled from a cost map)
 
 
 def algorithmic_bytes(c, width, height):
@@ -72,6 +87,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-config5", action="store_true", help="N > 1: skip the smallpt x 256 paths sub-record (BASELINE.json's 8-GPU configuration)")
     ap.add_argument("--accel", default="reference", choices=["reference", "sah"],
                     help="kd-trees walked by the timed frames: the reference's own (default) or the module's SAH rebuild")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not start the rocprofv3 --pmc child passes (roofline then comes from the committed profile, if it matches this checkout)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # what the counter passes run: a few frames of the workload, nothing else
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="launch / join the ranks, agree on the world size over gloo, print it and stop before any GPU work (CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -107,11 +124,140 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def kernel_build_id():
+    """Identifies the kernel sources and their build flags: sha256 over hexray_amd/csrc/* and build.sh (first 16 hex digits).  A committed
+    PMC profile carries the id it was taken on; bench.py uses it only when the ids match."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hexray_amd", "csrc")
+    for name in sorted(os.listdir(d)) + ["../../build.sh"]:
+        path = os.path.normpath(os.path.join(d, name))
+        if os.path.isfile(path):
+            h.update(name.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_child(args):
+    """What one counter pass runs under rocprofv3: a few frames of the workload through the C ABI into a host buffer (no torch)."""
+    import hexray_amd as hx
+    scene_name, ov, _ = WORKLOADS[args.workload]
+    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+    hx.init(0)
+    ds = hx.DeviceScene(hs, accel=hx.ACCEL_SAH if args.accel == "sah" else hx.ACCEL_REFERENCE)
+    params = hx.frame_params(tile_size=TILE)
+    for _ in range(PMC_CHILD_FRAMES):
+        ds.render(params)
+    print("pmc child: last kernel ms %.4f" % ds.last_kernel_ms())
+
+
+def live_pmc(args):
+    """The counters of the render kernel for this workload, collected NOW: one `rocprofv3 --pmc` child process per pass of PMC_PASSES, started
+    before this process has loaded torch or touched the GPU.  Returns {counter: value of the last render-kernel dispatch} or None with a reason."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    work = tempfile.mkdtemp(prefix="hxr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for tag, counters in PMC_PASSES:
+            d = os.path.join(work, tag)
+            cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                                                      "--workload", args.workload, "--accel", args.accel]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, "pass %s timed out" % tag
+            if r.returncode != 0:
+                return None, "pass %s: rocprofv3 exit %d: %s" % (tag, r.returncode, r.stdout.decode(errors="replace")[-300:].replace("\n", " | "))
+            rows = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "hxr_render_kernel" in row.get("Kernel_Name", ""):
+                        key = (row["Counter_Name"], int(row["Dispatch_Id"]))
+                        rows[key] = rows.get(key, 0.0) + float(row["Counter_Value"])
+            if not rows:
+                return None, "pass %s: no render-kernel rows in the counter CSV" % tag
+            last = max(k[1] for k in rows)
+            for (name, dispatch), v in rows.items():
+                if dispatch == last:
+                    out[name] = v
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    missing = [c for _, cs in PMC_PASSES for c in cs if c not in out]
+    if missing:
+        return None, "counters missing: %s" % " ".join(missing)
+    return out, "live: %d rocprofv3 --pmc child passes of this bench.py run (%d frames each, last dispatch read)" % (len(PMC_PASSES), PMC_CHILD_FRAMES)
+
+
+def committed_pmc(workload):
+    """The committed summary of the same counters (profiles/pmc_live_<workload>.json, written by tools/profile_collect.py from the round's profile run),
+    usable only when it was taken on the kernel sources of this checkout."""
+    path = os.path.join(ROOT, "profiles", "pmc_live_%s.json" % workload)
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, "no committed profile for this workload"
+    if rec.get("kernel_build") != kernel_build_id():
+        return None, "committed profile %s is of kernel build %s, this checkout is %s: not used" % (os.path.relpath(path, ROOT), rec.get("kernel_build"), kernel_build_id())
+    return rec["counters"], "committed profile %s (kernel build %s)" % (os.path.relpath(path, ROOT), rec["kernel_build"])
+
+
+def roofline_record(pmc, source, kernel_ms, abytes, samples_per_frame):
+    """The bench line's `roofline`: FP64 vector-ALU issue (what binds), with HBM traffic and SURVEY.md 8d's algorithmic-bytes line beside it."""
+    ksec = kernel_ms * 1e-3
+    rec = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+           "kernel": "hxr_render_kernel<false>", "kernel_ms": round(kernel_ms, 4), "source": source, "kernel_build": kernel_build_id()}
+    if pmc:
+        fma, mul, add = pmc["SQ_INSTS_VALU_FMA_F64"], pmc["SQ_INSTS_VALU_MUL_F64"], pmc["SQ_INSTS_VALU_ADD_F64"]
+        lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+        nominal = (2 * fma + mul + add) * 64.0          # flop per launch if every lane of every FP64 wave-instruction did useful work
+        useful = nominal * lane_util                     # ... scaled by the lanes that were switched on (all VALU instructions: the FP64 ones are not counted apart)
+        traffic = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0   # KB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section)
+        simd_cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0              # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs; SQ_ACTIVE_INST_* count quad-cycles
+        rec.update({
+            "achieved": round(useful / ksec / 1e12, 3), "frac": round(useful / ksec / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
+            "traffic": int(traffic),
+            "fp64_tflops_nominal": round(nominal / ksec / 1e12, 3), "frac_nominal": round(nominal / ksec / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
+            "valu_busy_frac": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 4), "valu_lane_util": round(lane_util, 4),
+            "salu_per_valu_instruction": round(pmc["SQ_INSTS_SALU"] / pmc["SQ_INSTS_VALU"], 3),
+            "hbm_measured_frac": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
+            "pmc": {k: pmc[k] for k in sorted(pmc)},
+            "note": "achieved = (2 FMA + MUL + ADD FP64 wave-instructions) x 64 x valu_lane_util / kernel time (HIP events of THIS run); "
+                    "counters are per launch (last dispatch of a counter pass); traffic = (2 FETCH_SIZE + WRITE_SIZE) KB: register-spill scratch, the tables stay in cache",
+        })
+    if abytes is not None:
+        achieved = abytes / ksec / 1e9
+        rec["hbm_algorithmic"] = {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                                  "algorithmic_bytes_per_launch": int(abytes), "bytes_per_sample": round(abytes / samples_per_frame, 2),
+                                  "note": "SURVEY.md 8d's algorithmic bytes (per-ray record sizes x this frame's work counters) priced against HBM peak: a side record -- "
+                                          "the packet walk fetches a record once per WAVE from cache-resident tables, so this line does not bind and can exceed 1"}
+    return rec
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     if launch_command(args, argv, 0) is not None:      # FIRST thing: no torch, no HIP call before the ranks exist
         raise SystemExit(self_launch(args, argv))
+    if args.pmc_child:
+        pmc_child(args)
+        return
+    pmc, pmc_source = None, "not collected"
+    if args.gpus == 1 and os.environ.get("WORLD_SIZE", "1") == "1" and not args.rendezvous_check:
+        # counter passes as child processes, BEFORE torch or the HIP module is loaded here (a process that has touched the GPU starts no other program)
+        if not args.no_live_pmc:
+            pmc, pmc_source = live_pmc(args)
+        if pmc is None:
+            why = pmc_source
+            pmc, pmc_source = committed_pmc(args.workload)
+            pmc_source = "%s (live collection: %s)" % (pmc_source, why)
 
     import numpy as np
     import torch
@@ -243,10 +389,14 @@ def main():
 
     # work counters of one frame (instrumented kernel build, outside the timed region)
     cparams = hx.frame_params(tile_size=TILE, collect_counters=True)
+    timed_equals_counted = None
     if world == 1:
+        timed_frame = frame.clone()                       # what the timed kernel wrote
         ds.render_device(cparams, frame.data_ptr(), W * 12, stream)
         torch.cuda.synchronize()
         counters = ds.counters()
+        timed_equals_counted = bool(torch.equal(timed_frame, frame))   # the timed variant did the counted variant's work: bit-equal frames
+        del timed_frame
     else:
         counters = None
 
@@ -295,30 +445,13 @@ def main():
         }
         if counters is not None:
             abytes = algorithmic_bytes(counters, W, H)
-            achieved = abytes / (kernel_ms_mean * 1e-3) / 1e9
             rays = counters["raycasts"] + counters["shadow_queries"]
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            result["roofline"] = {
-                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "bytes_per_sample": round(abytes / samples_per_frame, 2),
-                "kernel": "hxr_render_kernel<false>", "kernel_ms": round(kernel_ms_mean, 4),
-                # the algorithmic bytes are served by the scalar cache / L2 / Infinity Cache: what HBM itself moves is `traffic`
-                "hbm_measured_frac": round(traffic / (kernel_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "note": "frac prices the ALGORITHMIC bytes (SURVEY.md 8d) against HBM peak and can exceed what HBM moves: the tables live in cache.  "
-                        "hbm_measured_frac = PMC traffic / kernel time / peak; `compute` (PMC, profiles/) is the roofline that binds: instruction issue.",
-                "compute": compute_roofline(args.workload, kernel_ms_mean),
-            }
+            result["roofline"] = roofline_record(pmc, pmc_source, kernel_ms_mean, abytes, samples_per_frame)
+            result["timed_frame_equals_counted_frame"] = timed_equals_counted
             result["rays_per_sample"] = round(rays / counters["camera_samples"], 3)
             result["Mrays_per_s"] = round(rays / (kernel_ms_mean * 1e-3) / 1e6, 1)
         else:
-            result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                                  "kernel_ms": round(kernel_ms_mean, 4), "note": "per-rank kernel time of rank 0; counters are collected at N=1 only"}
+            result["roofline"] = roofline_record(None, "per-rank kernel time of rank 0; counters are collected at N=1 only", kernel_ms_mean, None, samples_per_frame)
         if config5 is not None:
             result["config5_smallpt256"] = config5
         if other is not None:
@@ -470,24 +603,6 @@ def other_timings(hx, hs, accel, W, H, stream, torch, np, frames):
         dq.close()
     except hx.HipError:
         pass
-    return out
-
-
-def compute_roofline(workload, kernel_ms):
-    """The roofline that binds (secondary): vector-ALU issue.  From the committed PMC summary of the same workload
-    (profiles/pmc_compute.json, written by tools/profile_collect.py from separate rocprofv3 --pmc passes) and THIS run's kernel time;
-    null when there is no summary for the workload."""
-    path = os.path.join(ROOT, "profiles", "pmc_compute.json")
-    try:
-        c = json.load(open(path)).get(workload)
-    except Exception:
-        return None
-    if not c:
-        return None
-    out = {k: c[k] for k in ("bound", "valu_busy_frac", "valu_lane_util", "peak_tflops", "profile")}
-    out["fp64_tflops_nominal"] = round(c["fp64_flop_per_launch_nominal"] / (kernel_ms * 1e-3) / 1e12, 3)
-    out["fp64_tflops_useful"] = round(c["fp64_flop_per_launch_useful"] / (kernel_ms * 1e-3) / 1e12, 3)
-    out["frac_of_fp64_peak"] = round(out["fp64_tflops_useful"] / c["peak_tflops"], 4)
     return out
 
 

@@ -30,10 +30,11 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	MESH_MC_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-memory-clause"   # the headline kernel (hxr_kernels_mesh_mc.hip): 6.57 ms, against 6.78 with max-ilp and 7.25 at -O2
 	HF_TU_FLAGS="-O1"    # the heightfield marcher at 3 waves per SIMD: -O1 keeps its spills out of the marching loop (7.77 ms against 9.04 at -O2)
 	NESTED_TU_FLAGS="-O2"
-	# NOT max-memory-clause for the catch-all unit, although it measured faster (kdtree_test 9.73 -> 9.23 ms): the Whitted catch-all
-	# built that way raised a GPU memory fault on the first frame of one generated scene (tests/test_gpu_fuzz.py, seed 24: anaglyph camera + CSG + mesh)
-	# that the max-ilp build renders correctly (with ONLY the API unit built that way the same tests pass: it is the catch-all kernel -- the largest of all,
-	# two inlined copies of the integrator for the anaglyph pair).  Cause not found, so that unit keeps the flags the whole GPU suite has passed with
+	# NOT max-memory-clause for the catch-all unit, although it measured faster (kdtree_test 9.73 -> 9.23 ms): with that strategy LLVM (ROCm 7.2) emits, in
+	# hxr_render_kernel<false, 239u, 3, -1> only, a live-range-split copy of cur_shader (`v_mov_b32 v66, v100`) at the head of a join block AHEAD of the
+	# `s_or_b64 exec, exec, s[2:3]` that closes the divergent region before it; the copy back runs under the full mask, so lanes that skipped the region get a
+	# stale shader index -- the GPU memory fault of fuzz seed 24 in round 3 (found in round 4 with rocgdb: profiles/r04_fault_seed24_rocgdb.txt; reproduce the
+	# defect without a GPU: tools/fault/reproduce_codegen_defect.sh).  The gate below (tools/check_exec_prologue.py) refuses ANY unit that carries the pattern.
 	MESH2_TU_FLAGS="-O2 -mllvm -amdgpu-sched-strategy=max-ilp"
 	MESH_GI_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-memory-clause"   # cornell16 48.2 -> 47.2 ms
 	API_TU_FLAGS="-O3 -mllvm -amdgpu-sched-strategy=max-memory-clause"        # holds the sphere path tracer: smallpt16 27.3 -> 26.7 ms
@@ -60,6 +61,10 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	wait $p5 || exit 1
 	wait $p6 || exit 1
 	hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip.so build/hxr_api.o build/hxr_kd_build.o build/hxr_kernels_mesh.o build/hxr_kernels_mesh_mc.o build/hxr_kernels_mesh2.o build/hxr_kernels_mesh_gi.o build/hxr_kernels_heightfield.o build/hxr_kernels_nested.o
+	# Gate (round 4): no kernel may hold a vector instruction between the label of a join block and the `s_or_b64 exec, exec, <saved mask>` that ends the
+	# divergent region before it.  That is the code-generation defect behind round 3's GPU memory fault (fuzz seed 24): built with max-memory-clause, the
+	# Whitted catch-all got a live-range-split copy of cur_shader there, which ran under the closed region's mask (tools/check_exec_prologue.py)
+	python3 tools/check_exec_prologue.py build/hxr_api.o build/hxr_kd_build.o build/hxr_kernels_mesh.o build/hxr_kernels_mesh_mc.o build/hxr_kernels_mesh2.o build/hxr_kernels_mesh_gi.o build/hxr_kernels_heightfield.o build/hxr_kernels_nested.o || { echo "build.sh: a kernel carries the exec-prologue defect: change that unit's flags" >&2; exit 1; }
 	# register / scratch / LDS footprint of the kernels bench.py's workloads run (code object metadata): the headline variant first
 	python3 tools/kernel_resources.py build/hxr_kernels_mesh_mc.o build/hxr_kernels_heightfield.o build/hxr_kernels_mesh_gi.o 2>/dev/null | grep -E "^kernel|<false, (1u, 4|4226u, 3|209u, 4), 1>" || true
 fi

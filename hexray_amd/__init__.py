@@ -59,11 +59,12 @@ class FrameTiming(ctypes.Structure):
     """hxr_frame_timing (include/hexray_hip.h)."""
 
     _fields_ = [("total_ms", c_double), ("render_ms", c_double), ("continue_ms", c_double), ("resolve_ms", c_double),
-                ("deferred_rays", c_uint64), ("reserved_", c_uint64 * 3)]
+                ("deferred_rays", c_uint64), ("sched_front_items", c_uint64), ("sched_back_items", c_uint64), ("sched_part_pixels", c_uint64)]
 
     def as_dict(self):
         return {"total_ms": self.total_ms, "render_ms": self.render_ms, "continue_ms": self.continue_ms, "resolve_ms": self.resolve_ms,
-                "deferred_rays": int(self.deferred_rays)}
+                "deferred_rays": int(self.deferred_rays), "sched_front_items": int(self.sched_front_items), "sched_back_items": int(self.sched_back_items),
+                "sched_part_pixels": int(self.sched_part_pixels)}
 
 
 class Counters(ctypes.Structure):

@@ -113,6 +113,7 @@ struct hxr_scene {
 	unsigned long long* d_sched_ctl = nullptr;                         // [0] total cost, then as uint32: [2] listed from the front, [3] from the back, [4] part slots, [5] ticket
 	struct SchedKey { int W, H, mode, spp, tile, rank, count; uint32_t chunks; } sched_key = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool sched_history = false;
+	bool sched_frame = false;           // the last frame went through prepare_schedule (hxr_frame_timing::sched_*)
 	bool aa_cost_aware = false;         // the last frame was an adaptive-AA frame whose flagged list has a back part
 	uint8_t* d_lut = nullptr;
 	// deferred secondary rays (HXR_F_DEFER variants; plan_defer)
@@ -813,6 +814,7 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	L.sched_part_groups = (int32_t)part_groups;
 	s->sched_key = key;
 	s->sched_history = true;
+	s->sched_frame = true;
 	return 0;
 }
 
@@ -843,6 +845,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	s->counters_valid = want_counter_buffer;
 	s->timed = false;
 	s->aa_cost_aware = false;
+	s->sched_frame = false;
 	HxrLaunch L;
 	fill_launch(s, p, L);
 	s->no_defer_this_frame = p.mode == HXR_MODE_PREPASS;
@@ -951,7 +954,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (tile_pixels) {
 		if (cost_aware) {
-			if (schedule_pass1) HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));   // pass 1's list counters are done with; the words now serve pass 3
+			if (schedule_pass1) { HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st)); s->sched_frame = false; }   // pass 1's list counters are done with; the words now serve pass 3
 			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
 			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
 		}
@@ -1954,6 +1957,13 @@ int hxr_get_frame_timing(const hxr_scene* s, hxr_frame_timing* out)
 #endif
 			if (ctl[2 * HXR_QUEUE_SHARDS * HXR_SHARD_STRIDE]) { set_err("the ray queue overflowed (internal error: it is sized for the worst case)"); return HXR_E_HIP; }
 		}
+	}
+	if (s->sched_frame && s->d_sched_ctl) {   // what prepare_schedule listed for this frame (the words are rewritten by the next frame only)
+		uint32_t w[16];
+		HIP_TRY(hipMemcpy(w, s->d_sched_ctl, sizeof w, hipMemcpyDeviceToHost));
+		out->sched_front_items = w[2];
+		out->sched_back_items = w[3];
+		out->sched_part_pixels = w[4];
 	}
 	if (s->passes_timed > 1) {   // the detect kernel between the passes of an adaptive-AA frame
 		float gap = 0;

@@ -444,7 +444,7 @@ template <int LEVEL>
 HXR_DEV void csg_rehit(const HxrSceneDev& S, const hxr_geometry& G, d3 o, d3 d, int k, d3& ip, d3& norm, double& u, double& v, int& prim_type)
 {
 	d3 start = o;
-	GeomHit g;
+	GeomHit g{HXR_INF, -1};   // defined even for k < 0 (an inner query that found nothing hands on tri = -1): no attribute below is read from indeterminate bits
 	bool nested = false;
 	if constexpr (LEVEL > 0) nested = is_csg(G.type);
 	for (int i = 0; i <= k; i++) {
@@ -1871,7 +1871,7 @@ HXR_DEV bool shard_pixel(const HxrLaunch& P, uint32_t q, int& x, int& y)
 		const uint32_t t0 = lt0 * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
 		int tx, ty;
 		hxr_tile_position((int)t0, P.tiles_x, P.shard_count, &tx, &ty);
-		if (lt != lt0) return false;   // cannot happen for a live lane
+		if (lt != lt0) return false;   // the lanes of a render-kernel packet, and 64 consecutive pixel numbers, lie in ONE tile; callers whose lanes do not use shard_pixel_general
 		const uint32_t blk = in >> 6;
 		int mx, my;
 		morton6(in & 63u, mx, my);
@@ -2453,7 +2453,9 @@ __global__ void hxr_sched_rects_kernel(HxrLaunch P, HxrRects R, uint32_t n, uint
 		const uint32_t first = i * ppc;
 		bool inside = false;
 		int x, y;
-		if (first < num_pixels && shard_pixel(P, first, x, y))
+		// (the general mapping: lane i asks for pixel i * ppc, so a wave spans 64 * ppc pixel numbers -- several tiles whenever that exceeds a tile, which
+		// shard_pixel()'s one-tile-per-wave shortcut does not serve: with it a first frame of 8-pixel shard tiles listed one chunk in 64)
+		if (first < num_pixels && shard_pixel_general(P, first, x, y))
 			for (int k = 0; k < R.n; k++) inside = inside || (x >= R.r[k][0] && x < R.r[k][2] && y >= R.r[k][1] && y < R.r[k][3]);
 		if (inside) {
 			if (quarters) {   // 1-spp packets (64 pixels): sixteen pixels per packet, so that 64 unrelated chains do not share one wave

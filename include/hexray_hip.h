@@ -475,7 +475,10 @@ typedef struct hxr_frame_timing {
 	double continue_ms;       /* hxr_continue_kernel: the deferred secondary rays; 0 when nothing is deferred */
 	double resolve_ms;        /* hxr_resolve_kernel (+ the AA detect kernel) */
 	uint64_t deferred_rays;   /* records the render kernel(s) appended to the ray queue */
-	uint64_t reserved_[3];
+	/* what the adaptive schedule listed for the frame's LAST scheduled pass (0 when the frame was not scheduled): items handed out from the front of the list
+	 * (pixels / sample parts of chunks that were expensive, whole chunks long against the frame), items at the back (whole chunks / runs of sixteen pixels that
+	 * only start first), pixels split by samples.  Diagnostics: the image never depends on them (they occupy what was reserved_[3]). */
+	uint64_t sched_front_items, sched_back_items, sched_part_pixels;
 } hxr_frame_timing;
 int hxr_get_frame_timing(const hxr_scene* scene, hxr_frame_timing* out);
 

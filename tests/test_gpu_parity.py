@@ -338,6 +338,24 @@ def test_adaptive_schedule_does_not_change_the_frame(gpu):
             assert c[k] == oc[k], (k, c[k], oc[k])
 
 
+def test_first_frame_schedule_lists_the_same_chunks_for_every_tile_size(gpu):
+    """A frame without history starts with the chunks inside the screen rectangles of the nodes that spawn secondary rays
+    (hxr_sched_rects_kernel).  Which chunks those are does not depend on how the frame is tiled: a chunk is 64 / spp consecutive pixel
+    numbers = an aligned block of the image for every tile size (a multiple of 8).  Round 3's one-tile-per-wave pixel mapping dropped the
+    lanes of that kernel that fell into another tile than lane 0's -- with 8-pixel tiles all but one chunk in 64."""
+    for ov, fp in ((hx.overlay_text(1920, 1080, dof=True, num_samples=16), dict()), (hx.overlay_text(1920, 1080, want_aa=False), dict(mode=hx.MODE_SINGLE))):
+        hs = hx.HostScene(scene_path("meshes.hexray"), ov)
+        listed, frames = {}, {}
+        for tile in (8, 32, 64):
+            ds = hx.DeviceScene(hs)                                   # a fresh handle: no cost map, the rectangles decide
+            frames[tile] = ds.render(hx.frame_params(tile_size=tile, **fp))
+            t = ds.frame_timing()
+            listed[tile] = (t["sched_front_items"], t["sched_back_items"])
+            ds.close()
+        assert listed[8][1] > 0 and listed[8] == listed[32] == listed[64], listed
+        assert np.array_equal(frames[8], frames[64]) and np.array_equal(frames[32], frames[64])
+
+
 def test_the_two_occupancies_of_the_monte_carlo_mesh_kernel_render_the_same_frame(gpu, monkeypatch):
     """The in-place Monte-Carlo mesh kernel is compiled for four and for three waves per SIMD, and the module takes one or the other by the
     launch's work per resident wave (mesh_mc_waves, hxr_api.hip).  Same source, other register budget: the frames -- first and scheduled --
