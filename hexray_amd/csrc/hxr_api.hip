@@ -536,6 +536,7 @@ int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place, uint32_t 
 // build; the queue is sized for the worst case (every lane of every packet of a dispenser range emits `fanout0` rays), so an
 // append can never fail, and a frame whose worst case does not fit HXR_QUEUE_MAX_RECORDS is traced in place as before.
 #define HXR_QUEUE_MAX_RECORDS (64ull << 20)   // 5 GB of 80-byte records
+#define HXR_SAH_DEVICE_MAX_TRIANGLES 65536   // largest mesh whose SAH tree the quadratic device builder takes (run: 9120 in 2.7 ms; ~50x the comparisons here)
 uint64_t defer_capacity(const hxr_scene* s, uint32_t num_chunks, int spp)   // records per sub-queue, 0 = this launch traces in place
 {
 	const Variant v = pick_variant(s);
@@ -1110,24 +1111,30 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 			if (const char* e = getenv("HXR_SAH_TRAVERSAL_COST")) sp.traversal_cost = atof(e);   // developer aids for tuning the cost model
 			if (const char* e = getenv("HXR_SAH_EMPTY_BONUS")) sp.empty_bonus = atof(e);
 			if (const char* e = getenv("HXR_SAH_MIN_LEAF")) sp.min_leaf = atoi(e);
-			if (getenv("HXR_SAH_HOST")) {   // the host builder (hxr_accel.h): what the device build is compared with
+			// The device build counts a node's candidates against all its triangles (N x 6N comparisons at the root): right for the reference's meshes (<= 9120
+			// triangles, 2.7 ms), tens of seconds at a million.  Above HXR_SAH_DEVICE_MAX_TRIANGLES, or when the device build cannot get its buffers, the
+			// O(N log N) host builder makes the same tree (hxr_accel.h).
+			bool on_host = getenv("HXR_SAH_HOST") != nullptr || m.num_triangles > HXR_SAH_DEVICE_MAX_TRIANGLES;
+			if (!on_host) {                 // built by kernels over the tables uploaded above (hxr_kd_build.hip)
+				char why[256] = "";
+				if (hxr_kd::build_sah_tree(d_tris + m.first_triangle, m.num_triangles, d_f64 + m.first_vertex * 3, m.bbox_min, m.bbox_max, sp.traversal_cost, sp.intersect_cost,
+				                           sp.empty_bonus, sp.max_depth, sp.min_leaf, built, why, sizeof why)) {
+					(void)hipGetLastError();   // e.g. an allocation that did not fit: the host builder needs none of it
+					on_host = true;
+				} else {
+					nodes = built.nodes.data();
+					leaf_idx = built.leaf_indices.data();
+					num_nodes = (int64_t)built.nodes.size();
+					num_leaf_entries = (int64_t)built.leaf_indices.size();
+					s->kd_build_ms += built.build_ms;
+				}
+			}
+			if (on_host) {                  // the host builder (hxr_accel.h): what the device build is compared with
 				hxr_sah::SahBuilder(d->triangles + m.first_triangle, m.num_triangles, d->f64_pool + m.first_vertex * 3, sp).build(m.bbox_min, m.bbox_max, sah);
 				nodes = sah.nodes.data();
 				leaf_idx = sah.leaf_indices.data();
 				num_nodes = (int64_t)sah.nodes.size();
 				num_leaf_entries = (int64_t)sah.leaf_indices.size();
-			} else {                        // the same tree built by kernels over the tables uploaded above (hxr_kd_build.hip)
-				char why[256] = "";
-				if (hxr_kd::build_sah_tree(d_tris + m.first_triangle, m.num_triangles, d_f64 + m.first_vertex * 3, m.bbox_min, m.bbox_max, sp.traversal_cost, sp.intersect_cost,
-				                           sp.empty_bonus, sp.max_depth, sp.min_leaf, built, why, sizeof why)) {
-					set_err("SAH build of mesh %lld: %s", (long long)i, why);
-					return fail();
-				}
-				nodes = built.nodes.data();
-				leaf_idx = built.leaf_indices.data();
-				num_nodes = (int64_t)built.nodes.size();
-				num_leaf_entries = (int64_t)built.leaf_indices.size();
-				s->kd_build_ms += built.build_ms;
 			}
 		}
 		if (accel == HXR_ACCEL_REFERENCE_DEVICE_BUILD && o.has_kd) {   // Mesh::buildKD as kernels, over the tables uploaded above

@@ -674,6 +674,7 @@ __global__ __launch_bounds__(KD_BLOCK) void sah_split_kernel(const SahTask* __re
 			if (n_left == count && n_right == count) leaf = true;   // the split separates nothing: a leaf after all
 		}
 		if (leaf) {
+			__syncthreads();   // every thread has read the split claim (s_claim, s_best_axis) before thread 0 rewrites the words for the leaf
 			if (tid == 0) {
 				const uint32_t first = atomicAdd(&ctl->leaf_cursor, count);
 				const bool fits = first + count <= caps.leaf;
@@ -906,7 +907,8 @@ int build_reference_tree(const hxr_triangle* d_tris, int64_t num_triangles, cons
 int build_sah_tree(const hxr_triangle* d_tris, int64_t num_triangles, const double* d_vertices, const double bbox_min[3], const double bbox_max[3],
                    double traversal_cost, double intersect_cost, double empty_bonus, int max_depth, int min_leaf, DeviceBuiltTree& out, char* err, size_t err_len)
 {
-	if (num_triangles < 0 || num_triangles > (1ll << 24)) { say(err, err_len, "SAH build: %lld triangles not supported", (long long)num_triangles); return HXR_E_INVALID; }
+	// quadratic in a node's triangles: the callers send larger meshes to the host builder (HXR_SAH_DEVICE_MAX_TRIANGLES, hxr_api.hip); 2^17 is the most ever run here
+	if (num_triangles < 0 || num_triangles > (1ll << 17)) { say(err, err_len, "SAH build on the device: %lld triangles not supported", (long long)num_triangles); return HXR_E_INVALID; }
 	const uint32_t n = (uint32_t)num_triangles;
 	const SahCosts K{traversal_cost, intersect_cost, empty_bonus, max_depth, min_leaf};
 	uint64_t scale = 1;

@@ -26,11 +26,7 @@
 #define HXR_RAY_STACK 12              // pending secondary rays per lane (checked against the scene at create time)
 #define HXR_SHADER_STACK 8            // pending (shader, weight) pairs while a hit is being shaded
 #define HXR_DEV __device__ __forceinline__
-#ifdef HXR_NOINLINE_HELPERS
-#define HXR_DEVX __device__ __noinline__
-#else
 #define HXR_DEVX __device__ __forceinline__
-#endif
 
 // Kernel specialisation.  The register allocation of a kernel is set by its hungriest code path, whether or not
 // a scene ever runs it (the heightfield marcher alone wants 96 VGPRs, the packet kd walk 60), so the render
@@ -557,17 +553,12 @@ HXR_DEV void tri_products(d3 N, d3 A, d3 AB, d3 AC, d3 o, d3 nd, double& Dcr, do
 	Dcr = dot(N, nd);
 	d3 H = o - A;
 	ga = dot(N, H);
-#ifdef HXR_TRI_TWO_CROSSES   // the reference's expressions, operation for operation
-	gb = dot(cross(H, AC), nd);
-	gc = dot(cross(AB, H), nd);
-#else
 	// (H x AC) . nd = (nd x H) . AC  and  (AB x H) . nd = -(nd x H) . AB: one cross product serves both numerators (21 operations per
 	// triangle instead of 27).  The same real numbers rounded along another path: gamma (= ga / Dcr, untouched) stays bit-identical, the
 	// barycentrics move in their last bits -- a decision differs from the reference's only for a ray within an ulp of a triangle's edge.
 	const d3 P = cross(nd, H);
 	gb = dot(P, AC);
 	gc = -dot(P, AB);
-#endif
 }
 
 // BBox::inside (src/bbox.h:78-85) with the slack handed in: the leaf loop passes an OPAQUE 1e-6 so that the six inflated bounds are
@@ -600,23 +591,10 @@ HXR_DEV bool triangle_test(const HxrSceneDev& S, const HxrMeshDev& M, const HxrT
 // The rest of Mesh::intersectTriangle once the four products are known (see triangle_test); `facing`: not culled as a back face
 HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, double gc, int hot, const Box& box, d3 o, d3 d, GeomHit& g)
 {
-#ifdef HXR_TRI_PLAIN_DECIDE
-	const bool neg = Dcr < 0;
-	bool ok = facing & !(fabs(Dcr) < 1e-12)
-	        & !(((ga < 0) != neg) & (ga != 0))    // gamma < 0
-	        & !(((gb < 0) != neg) & (gb != 0))    // lambda2 < 0
-	        & !(((gc < 0) != neg) & (gc != 0));   // lambda3 < 0
-#else
 	// "x * rD < 0" <=> x is non-zero and its sign differs from Dcr's <=> x times (1 with Dcr's sign) is < 0 -- an exact product, and a zero
 	// of either sign is not < 0: three multiplications and the comparisons, instead of two comparisons per numerator and mask arithmetic
-#ifdef HXR_TRI_SIGN_XOR
-	const int flip = __double2hiint(Dcr) & (int)0x80000000u;
-	const double sa = __hiloint2double(__double2hiint(ga) ^ flip, __double2loint(ga)), sb = __hiloint2double(__double2hiint(gb) ^ flip, __double2loint(gb)),
-	             sc = __hiloint2double(__double2hiint(gc) ^ flip, __double2loint(gc));
-#else
 	const double sgn = copysign(1.0, Dcr);
 	const double sa = ga * sgn, sb = gb * sgn, sc = gc * sgn;
-#endif
 	// (the two spellings compile to different mask code; each translation unit takes the one its kernels measured faster with:
 	// meshes16 7.52 -> 7.37 ms with the short-circuit form and 7.47 with the bitwise one, cornell16 53.4 -> 54.2 and 52.2)
 #ifdef HXR_TRI_DECIDE_BITWISE
@@ -625,20 +603,14 @@ HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, doub
 	const bool behind = (sa < 0) || (sb < 0) || (sc < 0);   // gamma, lambda2, lambda3 < 0
 	bool ok = facing && !(fabs(Dcr) < 1e-12) && !behind;
 #endif
-#endif
 	bool inside = false;
 	if (ok) {
 		double rD = 1 / Dcr;
 		double gamma = ga * rD, l2 = gb * rD, l3 = gc * rD;
-#ifdef HXR_TRI_PLAIN_DECIDE
-		double l1 = 1 - (l2 + l3);
-		bool take = !(gamma < 0 || gamma > g.t) & !(l2 < 0 || l2 > 1) & !(l3 < 0 || l3 > 1) & !(l1 < 0 || l1 > 1);
-#else
 		// gamma, l2, l3 are >= 0 here: rD has Dcr's sign, and a product has the product of the signs.  Then l1 = 1 - (l2 + l3) <= 1, and
 		// l1 < 0 <=> l2 + l3 > 1 (for a sum above 1 the difference is exact), which also bounds l2 and l3 by 1 (a rounded sum is no smaller
 		// than either non-negative term): the eight bounds of Mesh::intersectTriangle (src/mesh.cpp:189-193) come down to these two.
 		bool take = !(gamma > g.t) & !(l2 + l3 > 1);
-#endif
 		if (take) {
 			g.t = gamma;
 			g.tri = hot;
@@ -1011,11 +983,7 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 		if (marching && !need_tri) {
 			x0 = (int)floor(p.x);
 			z0 = (int)floor(p.z);
-#ifdef HXR_HF_BRANCHY
-			if (x0 < 0 || x0 >= F.W || z0 < 0 || z0 >= F.H) {
-#else
 			if (((unsigned)x0 >= (unsigned)F.W) | ((unsigned)z0 >= (unsigned)F.H)) {   // one comparison per coordinate, no nested masks
-#endif
 				marching = false;
 			} else {
 				const size_t cell = (size_t)z0 * F.W + x0;   // (x0, z0) is in range here: no clamping needed
@@ -1041,11 +1009,9 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 							k += passing ? 1 : 0;
 						}
 					}
-#ifndef HXR_HF_ONE_STAGE
 					// two probes per step on average (hf_stats): levels 4..7 -- half of the record and of the comparisons -- only when some lane of the
 					// wave has passed level 3, i.e. is about to skip eight cells or more
 					if (hxr_ballot(passing))
-#endif
 					{
 						const Levels4 hi = *(const HXR_GLOBAL Levels4*)(hm + 4);
 						const float lv[4] = {hi.x, hi.y, hi.z, hi.w};
@@ -1059,23 +1025,6 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 					tl.add(HC_HFHIGH, k < F.max_k ? k : F.max_k - 1);   // probes made: every passed level plus the failed one
 					k--;
 				}
-#ifdef HXR_HF_BRANCHY
-				if (k > 0) {
-					p = p + step * (double)(1 << k);
-					marching = box_holds(box, p);
-				} else {
-					double lx = d.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
-					double lz = d.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
-					pn = p + step * (fmin(lx, lz) + 1e-6);
-					tl.add(HC_HFHEIGHT);
-					if (fmin(p.y, pn.y) < cell_max) {
-						need_tri = true;
-					} else {
-						p = pn;
-						marching = box_holds(box, p);
-					}
-				}
-#else
 				// the skip of 2^k cells and the step to the next cell border are the same statement with another length: formed once, for
 				// lanes of both kinds (a wave usually holds both, and then ran both branches)
 				const double lx = d.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
@@ -1088,7 +1037,6 @@ HXR_DEV bool heightfield_query(const HxrHeightfieldDev& F, d3 o, d3 d, GeomHit& 
 					p = pn;
 					marching = box_holds(box, p);
 				}
-#endif
 			}
 		}
 		const uint64_t waiting = hxr_ballot(need_tri);
@@ -1524,10 +1472,6 @@ HXR_DEV int scene_query(const HxrSceneDev& S, d3 o, d3 d, double limit, bool any
 {
 	int node = -1;
 	bw = limit;
-#ifdef HXR_STUB_QUERY   // developer aid: measure the integrator's own register footprint
-	if (o.x * d.y > limit) { bw = o.z; bg.t = d.x; bg.tri = (int)o.y; return 0; }
-	return -1;
-#endif
 	for (int ni = 0; ni < S.num_nodes; ni++) {
 		GeomHit g;
 		double w;
@@ -1654,13 +1598,9 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 	constexpr bool gather_records = gi;
 	constexpr bool rect = (F & HXR_F_RECT) != 0;   // RectLight code only where the scene has one
 	constexpr bool defer = (F & HXR_F_DEFER) != 0; // secondary rays go to the queue: `top` stays 0, the stack is never touched
-#ifdef HXR_LIGHTS_IN_REGS
-	constexpr bool lights_from_table = false;
-#else
 	// Whitted variants without RectLights: a light sample is the PointLight's position and colour -- functions of the light's index alone --
 	// so they are read from the light's record where they are used instead of living in nine vector registers across the traversal
 	constexpr bool lights_from_table = !gi && !rect;
-#endif
 	constexpr bool one = (F & HXR_F_STACK1) != 0;  // at most one pending ray: it waits in LDS (st.pend)
 	constexpr int lds_slots = (F & HXR_F_LDSSTACK) != 0 ? HXR_LDS_RAY_SLOTS : 0;   // stack entries 0 .. lds_slots-1 live in LDS (st.pend), the rest in `stack`
 	static_assert(lds_slots == 0 || (!gi && !glossy && !defer && !one), "the LDS stack entries are for the in-place Whitted variants without glossy generators");
@@ -1669,10 +1609,6 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 	StackItem<glossy> stack[(defer || one) ? 1 : HXR_RAY_STACK - lds_slots];
 	const int pend_lane = threadIdx.x & 63;
 	auto pend_store = [&](const RayItem& r, int slot = 0) {   // HXR_F_STACK1 / HXR_F_LDSSTACK: a pending ray, one LDS row per dword (conflict-free)
-#ifdef HXR_PEND_IN_REGS
-		stack[0].r = r;
-		return;
-#endif
 		uint32_t* p = st.pend + slot * (HXR_PEND_DWORDS * 64) + pend_lane;
 		const double v[6] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z};
 #pragma unroll
@@ -1689,9 +1625,6 @@ HXR_DEV f3 trace_rays(const HxrSceneDev& S, const RayItem& start, const RngCtx& 
 		p[17 * 64] = r.key;
 	};
 	auto pend_load = [&](int slot = 0) {
-#ifdef HXR_PEND_IN_REGS
-		return stack[0].r;
-#endif
 		const uint32_t* p = st.pend + slot * (HXR_PEND_DWORDS * 64) + pend_lane;
 		double v[6];
 #pragma unroll
