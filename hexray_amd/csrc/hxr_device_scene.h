@@ -196,4 +196,9 @@ struct HxrLaunch {
 	// foveated rendering (src/main.cpp:284-311): mode 0 fills 8x8 blocks whose centre is farther than fov_radius from (vip_x, vip_y)
 	// with the mean of five rays; the detect kernel only flags pixels inside the radius.  fov_radius 0 = off.
 	int32_t fov_radius, vip_x, vip_y;
+	// 1: packets handed out from the FRONT of the schedule (split pixels, sample parts, chunks long against the frame) raise their wave's issue priority
+	// (s_setprio) for their duration.  Set for launches that are a few packets deep per resident wave (shards of a multi-GPU frame): there one long chain
+	// is what the launch waits for, and the arbiter lets it run at nearly the speed of a wave alone on its SIMD (8-way slowest rank 1.65 -> 1.51 ms); a whole
+	// frame loses 2.5 % of throughput by it and leaves it off.
+	int32_t front_priority;
 };

@@ -59,8 +59,19 @@ enum : unsigned {
 	// 64 lanes per dword), the rest -- reached only by hits stacked deeper than that -- in the scratch array as before.  For the variants
 	// compiled for two waves per SIMD, which leave the LDS of a CU idle (the heightfield variant: every water hit pushes a reflected and
 	// a refracted ray, 2.4 GB of scratch writes per frame before this).
-	HXR_F_LDSSTACK = 4096u
+	HXR_F_LDSSTACK = 4096u,
+	// Leaf loop of the packet walk: the hot record of triangle i + 1 is touched (one dword of each of its two cache lines, into two scratch scalar registers)
+	// as soon as triangle i's products are formed, so that the next iteration's scalar loads hit the scalar cache instead of L2.  For the instances that run
+	// launches a few packets deep (shards of a multi-GPU frame, first frames): there a packet's dependent chain is what the launch waits for and 28 % of a lone
+	// wave's chain is the wait for hot records (profiles/r04_chain_*.txt): slowest 8-way rank 1.51 -> 1.36 ms, the 3-waves instance 7.04 -> 6.72 ms per whole
+	// frame.  The throughput instance (four waves per SIMD) LOSES 6 % by it (128 spilled registers instead of 65) and stays without.
+	HXR_F_TOUCH = 8192u
 };
+#ifdef HXR_LEAF_TOUCH   // A/B aid: every kernel of the unit
+#define HXR_TOUCH_ALL true
+#else
+#define HXR_TOUCH_ALL false
+#endif
 #ifndef HXR_LDS_RAY_SLOTS
 #define HXR_LDS_RAY_SLOTS 2   // 2 x 18 dwords x 256 lanes = 36 KB per block: three blocks per CU (3 waves per SIMD) fit the 160 KB; 4 slots (72 KB) allow two
 #endif
@@ -84,6 +95,10 @@ HXR_DEV d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
 #define HXR_GLOBAL __attribute__((address_space(1)))
 template <class T> HXR_DEV const HXR_GLOBAL T* in_hbm(const T* p) { return (const HXR_GLOBAL T*)p; }
 HXR_DEV d3 ld3(const HXR_GLOBAL double* p) { return d3{p[0], p[1], p[2]}; }
+// ... and tables that nothing writes while a kernel runs can be read through the CONSTANT address space: a wave-uniform load from it is a scalar load
+// whatever stands between it and the kernel's entry (an inline asm, a store the compiler cannot tell apart)
+#define HXR_CONSTANT __attribute__((address_space(4)))
+HXR_DEV d3 ld3(const HXR_CONSTANT double* p) { return d3{p[0], p[1], p[2]}; }
 HXR_DEV d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 HXR_DEV d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 HXR_DEV d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
@@ -153,8 +168,25 @@ HXR_DEV bool is_zero(f3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 enum { PH_DISPENSE, PH_GEN, PH_QUERY, PH_MESH, PH_LEAF, PH_SHADE, PH_NUM, PH_REDUCE = PH_GEN, PH_SURFACE = PH_SHADE, PH_ENDS = PH_SHADE, PH_MAP = PH_GEN, PH_LENS = PH_GEN };
 #elif HXR_PHASE_SET == 2                            // everything around the traversal in detail
 enum { PH_DISPENSE, PH_GEN, PH_REDUCE, PH_QUERY, PH_ENDS, PH_SHADE, PH_NUM, PH_MESH = PH_QUERY, PH_LEAF = PH_QUERY, PH_SURFACE = PH_SHADE, PH_MAP = PH_GEN, PH_LENS = PH_GEN };
-#else                                               // sample generation in detail
+#elif HXR_PHASE_SET == 3                            // sample generation in detail
 enum { PH_DISPENSE, PH_MAP, PH_LENS, PH_GEN, PH_REDUCE, PH_QUERY, PH_NUM, PH_MESH = PH_QUERY, PH_LEAF = PH_QUERY, PH_SURFACE = PH_QUERY, PH_ENDS = PH_QUERY, PH_SHADE = PH_QUERY };
+#else                                               // the dependent chain of the kd walk (round 4): what a step computes against what it waits for
+// PH_DISPENSE = everything outside Mesh::intersect; inside it: PH4_KD_COMPUTE the children's box tests, ballots, pushes; PH4_KD_WAIT what is left of the
+// wait for the children's records (in flight during the tests) / for a popped node's record and box; PH4_LEAF_WAIT the wait for a triangle's hot record;
+// PH4_LEAF_COMPUTE its test; PH4_POP looking for the next pending visit
+enum { PH_DISPENSE, PH4_KD_COMPUTE, PH4_KD_WAIT, PH4_LEAF_WAIT, PH4_LEAF_COMPUTE, PH4_POP, PH_NUM, PH_GEN = PH_DISPENSE, PH_QUERY = PH_DISPENSE, PH_MESH = PH4_POP,
+       PH_LEAF = PH4_LEAF_COMPUTE, PH_SHADE = PH_DISPENSE, PH_REDUCE = PH_DISPENSE, PH_SURFACE = PH_DISPENSE, PH_ENDS = PH_DISPENSE, PH_MAP = PH_DISPENSE, PH_LENS = PH_DISPENSE };
+#define HXR_CHAIN_LAPS 1
+#endif
+// HXR_CHAIN_LAP(tl, PHASE, words...): (chain profile only) first make the listed scalar words arrive -- an empty asm that takes them as inputs: the compiler
+// must wait for their loads before it, which neither s_waitcnt nor a scheduling barrier achieves for constant-address-space loads -- then charge the time
+// since the last lap to PHASE
+#ifdef HXR_CHAIN_LAPS
+#define HXR_CHAIN_ARRIVE2(a, b) asm volatile("" ::"s"(a), "s"(b))
+#define HXR_CHAIN_LAP(tl, PHASE) (tl).template lap<PHASE>()
+#else
+#define HXR_CHAIN_ARRIVE2(a, b) ((void)0)
+#define HXR_CHAIN_LAP(tl, PHASE) ((void)0)
 #endif
 
 template <bool COUNT>
@@ -632,7 +664,7 @@ HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, doub
 // and stay in SGPRs, so a triangle costs the lanes no vector registers.  The triangle NUMBER of a record (hot_ids) is not read
 // here: a hit remembers its record, surface_of() looks the number up for the one hit a ray keeps.
 // `mask`: the lanes taking part (wave-uniform); returns the lanes that found a hit inside the leaf's box.
-template <bool COUNT>
+template <bool COUNT, bool TOUCH>
 HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, unsigned long long mask, const Box& box, d3 o, d3 d, d3 nd,
                                       GeomHit& g, Tally<COUNT>& tl)
 {
@@ -658,6 +690,7 @@ HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M,
 	const int base = M.hot_first + first;
 	const HxrTriHot* T = S.hot + base;
 	int hits = 0;   // per lane, touched only where a triangle is accepted: no mask bookkeeping per iteration
+	[[maybe_unused]] uint32_t touch0 = 0, touch1 = 0;   // TOUCH: the scratch registers of the prefetch
 	if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
 		if (M.backface_culling) {
 			for (int i = 0; i < count; i++) {
@@ -669,7 +702,27 @@ HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M,
 			for (int i = 0; i < count; i++) {
 				tl.add(HC_TRI);
 				tl.add(HC_LEAFIDX);
-				hits |= (int)triangle_test<false>(S, M, T[i], base + i, box, o, d, nd, g);
+#if defined(HXR_CHAIN_LAPS)
+				const HxrTriHot rec = T[i];
+				HXR_CHAIN_ARRIVE2(rec.A[0], rec.N[2]);   // first and last word of the 96-byte record
+				HXR_CHAIN_LAP(tl, PH4_LEAF_WAIT);
+				hits |= (int)triangle_test<false>(S, M, rec, base + i, box, o, d, nd, g);
+				HXR_CHAIN_LAP(tl, PH4_LEAF_COMPUTE);
+#else
+				if constexpr (TOUCH) {
+					// HXR_F_TOUCH.  The record is read through the constant address space, or the inline asm below (a possible store, to the compiler) would turn
+					// the loads behind it into vector loads.  The touch registers are consumed one iteration later, behind that iteration's wait for its own
+					// record (scalar loads return out of order: one counter, one wait for all), so they stay reserved until the touch has landed.
+					double Dcr, ga, gb, gc;
+					const HXR_CONSTANT HxrTriHot* Tc = (const HXR_CONSTANT HxrTriHot*)(T + i);
+					tri_products(ld3(Tc->N), ld3(Tc->A), ld3(Tc->AB), ld3(Tc->AC), o, nd, Dcr, ga, gb, gc);
+					asm volatile("" ::"s"(touch0), "s"(touch1), "v"(Dcr));
+					if (i + 1 < count) asm volatile("s_load_dword %0, %2, 0x60\n\ts_load_dword %1, %2, 0xa0" : "=&s"(touch0), "=&s"(touch1) : "s"(T + i));
+					hits |= (int)triangle_decide(true, Dcr, ga, gb, gc, base + i, box, o, d, g);
+				} else {
+					hits |= (int)triangle_test<false>(S, M, T[i], base + i, box, o, d, nd, g);
+				}
+#endif
 			}
 		}
 	}
@@ -741,7 +794,7 @@ HXR_DEV void kd_children_hit(const Box& b, int axis, double split, d3 o, d3 inv,
 // its best hit.  The work counters are per lane and equal the reference's per-ray counts: a lane's test of its NEAR child is
 // counted when the node is entered, that of its FAR child when that child's turn comes and the lane is still searching (`due`
 // masks, instrumented builds only) -- exactly when the reference makes it.
-template <bool COUNT>
+template <bool COUNT, bool TOUCH>
 HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, const Stacks& st, Tally<COUNT>& tl)
 {
 	tl.template lap<PH_QUERY>();
@@ -757,7 +810,7 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	if (!alive) { tl.template lap<PH_MESH>(); return false; }
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
-		leaf_query<COUNT>(S, M, 0, M.num_triangles, alive, everything, o, d, nd, g, tl);
+		leaf_query<COUNT, TOUCH>(S, M, 0, M.num_triangles, alive, everything, o, d, nd, g, tl);
 		tl.template lap<PH_MESH>();
 		return in_root && g.t < HXR_INF;
 	}
@@ -767,6 +820,8 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	unsigned long long mask = alive;   // lanes taking part in the visit of the current node
 	if (in_root) tl.add(HC_KD);
 	HxrKdSlim R = kd[0];               // record of the current node (scalar registers)
+	HXR_CHAIN_ARRIVE2(R.first, R.axis_count);
+	HXR_CHAIN_LAP(tl, PH4_KD_WAIT);
 	for (;;) {
 		const int ac = R.axis_count;
 		const int axis = ac & 3;
@@ -775,7 +830,7 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) atomicAdd(S.dev_stats + 5, 1ull);   // walk steps
 #endif
 		if (axis == HXR_KD_LEAF) {
-			const unsigned long long here = leaf_query<COUNT>(S, M, R.first, ac >> 2, mask, cb, o, d, nd, g, tl);
+			const unsigned long long here = leaf_query<COUNT, TOUCH>(S, M, R.first, ac >> 2, mask, cb, o, d, nd, g, tl);
 			found |= here;
 			alive &= ~here;
 		} else {
@@ -807,7 +862,10 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 				if (COUNT) { st.wave->due_lo[sp] = (uint32_t)lm; st.wave->due_hi[sp] = (uint32_t)(lm >> 32); }
 				sp++;
 			}
+			HXR_CHAIN_LAP(tl, PH4_KD_COMPUTE);
 			if (first < 3) {
+				HXR_CHAIN_ARRIVE2(kids.kid[0].first, kids.kid[1].first);
+				HXR_CHAIN_LAP(tl, PH4_KD_WAIT);
 				// BBox::split (src/bbox.h:210-216): the child keeps the box and replaces one bound by the split position
 				const bool go_left = first != 1;
 				const int moved = go_left ? axis : axis + 3;   // which of the six bounds becomes the split position
@@ -842,6 +900,9 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			if (!m) continue;
 			R = kd[cn];
 			const HxrKdBox CB = kd_box[cn];
+			HXR_CHAIN_LAP(tl, PH4_POP);
+			HXR_CHAIN_ARRIVE2(R.first, CB.hi[2]);
+			HXR_CHAIN_LAP(tl, PH4_KD_WAIT);
 			cb = Box{ld3(CB.lo), ld3(CB.hi)};
 			mask = m;
 			if (COUNT && __builtin_amdgcn_inverse_ballot_w64(m)) tl.add(HC_KD);
@@ -1102,7 +1163,7 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 		case HXR_GEOM_MESH:
 			if constexpr ((F & HXR_F_MESH) != 0) {
 				if constexpr ((F & HXR_F_LANEWALK) != 0) return mesh_query_lane<COUNT>(S, S.meshes[N.ref], ol, dl, g, st.lane, tl);
-				else return mesh_query<COUNT>(S, S.meshes[N.ref], ol, dl, g, st, tl);
+				else return mesh_query<COUNT, (F & HXR_F_TOUCH) != 0 || HXR_TOUCH_ALL>(S, S.meshes[N.ref], ol, dl, g, st, tl);
 			}
 			return false;
 		case HXR_GEOM_HEIGHTFIELD:
@@ -1944,11 +2005,12 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			if (__builtin_amdgcn_readfirstlane(stop)) break;
 		}
 		uint32_t single_pixel = 0xffffffffu;   // != ~0: this packet renders only that pixel
+		bool from_front = false;               // ... handed out from the front of the schedule: split pixels / sample parts, chunks long against the frame
 		if (listed_left) {
 			uint32_t t = 0;
 			if (lane == 0) t = atomicAdd(P.sched_ticket, 1u);
 			t = __builtin_amdgcn_readfirstlane(t);
-			if (t < listed_a) single_pixel = P.sched_items[t];
+			if (t < listed_a) { single_pixel = P.sched_items[t]; from_front = true; }
 			else if (t - listed_a < listed_b) single_pixel = P.sched_items[P.sched_capacity - 1u - (t - listed_a)];
 			else listed_left = false;
 		}
@@ -1976,6 +2038,9 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		tl.template lap<PH_DISPENSE>();
 		const unsigned long long packet_t0 = __builtin_readcyclecounter();
 		const bool listed = single_pixel != 0xffffffffu;
+		if (P.front_priority) {   // (wave-uniform) see HxrLaunch::front_priority
+			if (from_front || (P.front_priority > 1 && listed)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+		}
 		const bool part = listed && (single_pixel & HXR_SCHED_PART);        // HXR_PART_LANES samples of one pixel
 		const uint32_t part_slot = single_pixel & 0x3fffffu, part_group = (single_pixel >> 22) & 0xffu;
 		if (part) single_pixel = P.sched_part_pixels[part_slot];
@@ -2444,22 +2509,43 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, c
 {
 	const unsigned long long heavy_above = cost ? (unsigned long long)heavy_x * (*total / (cost_chunks ? cost_chunks : 1u)) : ~0ull;
 	uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
-	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < ((tile_pixels + 63u) & ~63u); q += gridDim.x * blockDim.x) {
-		int x, y;
+	// An unsharded frame is walked ROW-MAJOR (round 4): a wave then reads three contiguous 768-byte runs of the frame instead of an 8x8 block's 24 short rows
+	// (155 -> ~40 us at 1920x1080: the pass between the two render passes of an adaptive-AA frame); the pixel's number in shard order, which indexes the
+	// pass-1 cost map, is formed from (x, y).  Shards keep the tile order: their pixels are not a rectangle.  The ORDER of the flagged list differs between
+	// the two walks (it is unordered anyway: one atomic per wave); which pixels are flagged does not.
+	const bool row_major = P.shard_count == 1;
+	const uint32_t span = row_major ? (uint32_t)(P.W * P.H) : tile_pixels;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ((span + 63u) & ~63u); i += gridDim.x * blockDim.x) {
+		int x = 0, y = 0;
+		uint32_t q = i;
+		bool mine = false;
+		if (row_major) {
+			mine = i < span;
+			x = (int)(i % (uint32_t)P.W);
+			y = (int)(i / (uint32_t)P.W);
+			const int ts = P.tile_size, lx = x % ts, ly = y % ts;
+			const uint32_t m = (uint32_t)((lx & 1) | ((ly & 1) << 1) | ((lx & 2) << 1) | ((ly & 2) << 2) | ((lx & 4) << 2) | ((ly & 4) << 3));
+			q = (uint32_t)((y / ts) * P.tiles_x + x / ts) * (uint32_t)(ts * ts) + (uint32_t)((ly >> 3) * (ts >> 3) + (lx >> 3)) * 64u + m;
+		} else {
+			mine = i < tile_pixels && shard_pixel(P, i, x, y);
+		}
 		bool need = false;
 		// src/main.cpp:201,205: with a fovea only pixels inside it are candidates
-		if (q < tile_pixels && shard_pixel(P, q, x, y) &&
-		    !((x - P.vip_x) * (x - P.vip_x) + (y - P.vip_y) * (y - P.vip_y) > (P.fov_radius > 0 ? P.fov_radius * P.fov_radius : 999666111))) {
+		if (mine && !((x - P.vip_x) * (x - P.vip_x) + (y - P.vip_y) * (y - P.vip_y) > (P.fov_radius > 0 ? P.fov_radius * P.fov_radius : 999666111))) {
 			const float* me = (const float*)((const char*)frame + (size_t)y * stride) + (size_t)x * 3;
-			for (int dy = -1; dy <= 1 && !need; dy++)
-				for (int dx = -1; dx <= 1 && !need; dx++) {
+			const float m0 = fminf(1.0f, me[0]), m1 = fminf(1.0f, me[1]), m2 = fminf(1.0f, me[2]);
+			float worst = 0.0f;   // the largest clamped difference to any neighbour in any channel: `> 0.075` for one of them <=> for the largest (no early exits: the lanes of a wave leave at different ones)
+#pragma unroll
+			for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+				for (int dx = -1; dx <= 1; dx++) {
 					if (!dx && !dy) continue;
-					int nx = x + dx, ny = y + dy;
+					const int nx = x + dx, ny = y + dy;
 					if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
 					const float* nb = (const float*)((const char*)frame + (size_t)ny * stride) + (size_t)nx * 3;
-					for (int c = 0; c < 3; c++)
-						if (fabsf(fminf(1.0f, me[c]) - fminf(1.0f, nb[c])) > 0.075f) { need = true; break; }
+					worst = fmaxf(worst, fmaxf(fabsf(m0 - fminf(1.0f, nb[0])), fmaxf(fabsf(m1 - fminf(1.0f, nb[1])), fabsf(m2 - fminf(1.0f, nb[2])))));
 				}
+			need = worst > 0.075f;
 		}
 		const bool heavy = need && cost && (unsigned long long)cost[q >> 6] > heavy_above;   // pass-1 chunks are 64 consecutive pixel numbers
 		unsigned long long mask = hxr_ballot(need && !heavy), hmask = hxr_ballot(heavy);

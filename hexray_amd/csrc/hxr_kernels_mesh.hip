@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "hexray_hip.h"
 #define HXR_RENDER_KERNEL_ONLY
+#define HXR_LEAF_TOUCH   // round 4: every kernel of this unit (three waves per SIMD, launches a few packets deep: 1-spp passes, adaptive-AA passes) prefetches the next hot record in its leaf loop (HXR_F_TOUCH): meshes 1 spp 1.08 -> 1.01 ms, simple 0.75 -> 0.72
 #include "hxr_kernels.hip.h"
 #include "hxr_variants.h"
 

@@ -29,13 +29,14 @@
 // resident waves (resident_waves_per_cu, hxr_api.hip).  The instances whose mode arrives at launch (adaptive anti-aliasing, prepass, interactive)
 // lose 10 % at four waves and stay at HXR_MESH_WAVES.  So does a launch with little work per resident wave -- a shard of an 8-GPU frame, a 1-spp frame:
 // there one packet's chain of dependent steps is what the frame waits for, and a fourth wave on the SIMD only stretches it (slowest 8-way rank
-// 1.62 ms at four waves, 1.44 at three): mesh_mc_waves() in hxr_api.hip picks the instance per launch.
+// 1.62 ms at four waves, 1.44 at three): mesh_mc_waves() in hxr_api.hip picks the instance per launch.  Round 4: the three-waves instance -- the latency
+// instance -- also prefetches the next hot record in its leaf loop (HXR_F_TOUCH: slowest 8-way rank 1.51 -> 1.36 ms; the throughput instance loses 6 % by it).
 #ifndef HXR_MESH_MC_WAVES
 #define HXR_MESH_MC_WAVES 4
 #endif
 #define HXR_VARIANTS_MESH_INPLACE_MC(X)          \
 	X(false, (HXR_F_MESH), HXR_MESH_MC_WAVES)              \
-	X(false, (HXR_F_MESH), HXR_MESH_WAVES)                 \
+	X(false, (HXR_F_MESH | HXR_F_TOUCH), HXR_MESH_WAVES)   \
 	X(false, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES) \
 	X(true, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES)
 // ... with at most one secondary ray pending per lane (no Layered shader of the scene has two Reflection / Refraction layers): the

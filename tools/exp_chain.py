@@ -9,7 +9,7 @@ import numpy as np
 import hexray_amd as hx
 hx.init(0)
 hs = hx.HostScene(os.path.join(ROOT, "data", "meshes.hexray"), hx.overlay_text(width=1920, height=1080, dof=True, num_samples=int(os.environ.get("SPP", "16"))))
-ds = hx.DeviceScene(hs, adaptive_schedule=False)
+ds = hx.DeviceScene(hs, adaptive_schedule=False, accel=hx.ACCEL_SAH if os.environ.get("HXR_ACCEL") == "sah" else hx.ACCEL_REFERENCE)
 st = torch.cuda.current_stream().cuda_stream
 buf = torch.zeros(32 * 32 * 3 + 64, dtype=torch.float32, device="cuda")
 
@@ -30,7 +30,11 @@ if os.environ.get("HXR_TILE8"):
     ph = list(ds.counters_raw().reserved_)[:6]
     names = os.environ.get("HXR_PHASE_NAMES", "dispense,gen(+reduce),query(nodes),mesh walk,leaf,shade").split(",")
     tot = sum(ph) or 1
-    print("8x8 tile %d: kernel %.3f ms; wave-clock shares:" % (t8, ms), "  ".join("%s %.1f%%" % (n, 100.0 * v / tot) for n, v in zip(names, ph)), flush=True)
+    print("8x8 tile %d: kernel %.3f ms; wave-clock shares:" % (t8, ms), "  ".join("%s %.1f%%" % (n, 100.0 * v / tot) for n, v in zip(names, ph)), " raw clocks", ph, flush=True)
+    if os.environ.get("HXR_CHAIN_COUNTS"):   # the same tile through the counting build of the SAME library: work per phase
+        tile_ms(8, t8, 240 * 135, counters=True, reps=1)
+        c = ds.counters()
+        print("  counters of that tile: samples %d raycasts %d shadow %d kd_visits %d bbox %d tri_tests %d" % (c["camera_samples"], c["raycasts"], c["shadow_queries"], c["kd_visits"], c["bbox_tests"], c["tri_tests"]), flush=True)
     sys.exit(0)
 
 times = np.array([tile_ms(32, t, 60 * 34, reps=1) for t in range(60 * 34)])
