@@ -22,6 +22,7 @@
 HXR_VARIANTS_MESH_DEFER(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_LAUNCH_MODE)
 HXR_VARIANTS_MESH_INPLACE_MC(HXR_DECLARE_EXTERN_MONTE_CARLO)
+HXR_VARIANTS_MESH_PARTS(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_STACK1(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_CONTINUE)
 HXR_VARIANTS_MESH_LANEWALK(HXR_DECLARE_EXTERN_CONTINUE)
@@ -112,6 +113,13 @@ struct hxr_scene {
 	uint32_t* d_sched_part = nullptr;                                  // [0..SLOTS) parts done, [SLOTS..2*SLOTS) pixel of the slot
 	unsigned long long* d_sched_ctl = nullptr;                         // [0] total cost, then as uint32: [2] listed from the front, [3] from the back, [4] part slots, [5] ticket
 	struct SchedKey { int W, H, mode, spp, tile, rank, count; uint32_t chunks; } sched_key = {0, 0, 0, 0, 0, 0, 0, 0};
+	// the replicating blocks (HXR_F_REPL instance) that take the schedule's sample parts and single pixels beside the kernel that renders the rest
+	uint32_t* d_sched_items_r = nullptr; size_t sched_items_r_cap = 0;
+	hipStream_t parts_stream = nullptr;
+	hipEvent_t ev_parts_go = nullptr, ev_parts_done = nullptr;
+	HxrLaunch parts_launch;             // its launch record, prepared with the schedule
+	bool parts_pending = false;         // ... and to be launched with the next render kernel
+	bool frame_counts = false;          // the frame being rendered collects work counters (the counting kernels take every packet themselves)
 	bool sched_history = false;
 	bool sched_frame = false;           // the last frame went through prepare_schedule (hxr_frame_timing::sched_*)
 	bool aa_cost_aware = false;         // the last frame was an adaptive-AA frame whose flagged list has a back part
@@ -463,6 +471,13 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 	L.cancel = s->watch_cancel;
 	L.tile_done = s->watch_tiles;
 	L.fov_radius = p.fovea; L.vip_x = p.vip_x; L.vip_y = p.vip_y;
+	L.no_replication = getenv("HXR_NO_REPLICATION") ? 1 : 0;
+}
+
+int parts_grid(const hxr_scene* s)   // blocks of the replicating instance launched beside the main kernel: an eighth of the machine at three waves per SIMD
+{
+	if (const char* e = getenv("HXR_PARTS_GRID")) return std::max(1, atoi(e));   // developer aid
+	return std::max(1, s->num_cu * HXR_MESH_WAVES / 8);
 }
 
 int grid_for(const hxr_scene* s, uint32_t chunks)
@@ -532,6 +547,29 @@ int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place, uint32_t 
 	}
 }
 
+int ensure_parts_stream(hxr_scene* s)   // the stream of the replicating blocks and the two events that tie it to the caller's stream
+{
+	if (s->parts_stream) return 0;
+	int lo = 0, hi = 0;
+	HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+	HIP_TRY(hipStreamCreateWithPriority(&s->parts_stream, hipStreamNonBlocking, hi));
+	HIP_TRY(hipEventCreateWithFlags(&s->ev_parts_go, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&s->ev_parts_done, hipEventDisableTiming));
+	return 0;
+}
+
+// Is there a replicated-packet kernel for this launch?  (Whitted over meshes without refraction, in place, uninstrumented; HXR_NO_PARTS_KERNEL=1: A/B aid)
+uint64_t defer_capacity(const hxr_scene* s, uint32_t num_chunks, int spp);
+bool parts_kernel_for(const hxr_scene* s, const HxrLaunch& L)
+{
+	if (getenv("HXR_NO_PARTS_KERNEL") || s->frame_counts || pick_variant(s) != V_MESH) return false;
+	if (defer_capacity(s, L.num_chunks, L.spp) != 0 || (s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr)) return false;
+	// launches that run the three-waves (latency) instances: 1-spp and AA passes, Monte-Carlo launches a few packets deep -- the replicating instance is one of them
+	// and shares the SIMDs with the others on equal terms; a whole Monte-Carlo frame (four waves of 128 registers) does not take it
+	if (L.mode == 1 && mesh_mc_waves(s, L.num_chunks) != HXR_MESH_WAVES) return false;   // (tried: 6.45 -> 8.2 ... 9.5 ms per whole frame)
+	return L.mode == 0 || L.mode == 1 || L.mode == 2;
+}
+
 // Deferred secondary rays: does this launch use them, and with what queue?  Only the Whitted mesh variants have a deferring
 // build; the queue is sized for the worst case (every lane of every packet of a dispenser range emits `fanout0` rays), so an
 // append can never fail, and a frame whose worst case does not fit HXR_QUEUE_MAX_RECORDS is traced in place as before.
@@ -587,9 +625,30 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 	s->pass_deferred[pass] = defer;
 	HIP_TRY(hipEventRecord(s->ev_pass[pass][0], st));
 	const HxrSceneDev& V = s->host_view;
-#define HXR_KERNEL_ARGS s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, L
+#define HXR_KERNEL_ARGS_OF(LAUNCH) s->dev, V.nodes, V.meshes, V.heightfields, V.bitmaps, V.textures, V.shaders, V.layers, V.lights, V.kd, V.kd_box, V.hot, V.hot_ids, V.geometries, LAUNCH
+#define HXR_KERNEL_ARGS HXR_KERNEL_ARGS_OF(L)
+	bool parts_launched = false;
+	if (s->parts_pending && !counters && !defer && L.num_chunks > 0) {
+		// the replicated-packet kernel first, on its own stream behind the schedule's kernels, so that its few hundred waves find room before the persistent
+		// waves of the main kernel fill the machine; the caller's stream waits for it after the main kernel
+		int rcs = ensure_parts_stream(s);
+		if (rcs) return rcs;
+		HIP_TRY(hipEventRecord(s->ev_parts_go, st));
+		HIP_TRY(hipStreamWaitEvent(s->parts_stream, s->ev_parts_go, 0));
+		const HxrLaunch& K = s->parts_launch;
+		const int pgrid = parts_grid(s);
+		if (K.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<false, (HXR_F_MESH | HXR_F_TOUCH | HXR_F_REPL), HXR_MESH_WAVES, 1>), dim3(pgrid), dim3(HXR_BLOCK), 0, s->parts_stream, HXR_KERNEL_ARGS_OF(K));
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<false, (HXR_F_MESH | HXR_F_TOUCH | HXR_F_REPL), HXR_MESH_WAVES, -1>), dim3(pgrid), dim3(HXR_BLOCK), 0, s->parts_stream, HXR_KERNEL_ARGS_OF(K));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(s->ev_parts_done, s->parts_stream));
+		parts_launched = true;
+	}
+	s->parts_pending = false;
 	if (L.num_chunks > 0) {
 		int grid = grid_for(s, L.num_chunks);
+		// beside the replicating blocks the main kernel is launched with exactly the blocks that fit the machine with them (three blocks of four waves per CU at
+		// three waves per SIMD): whichever kernel the dispatcher starts first, the other finds its room
+		if (parts_launched) grid = std::max(1, std::min(grid, s->num_cu * HXR_MESH_WAVES - parts_grid(s)));
 #define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                      \
 	do {                                                                                                                                                      \
 		if (L.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);     \
@@ -646,6 +705,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 #undef HXR_LAUNCH
 		HIP_TRY(hipGetLastError());
 	}
+	if (parts_launched) HIP_TRY(hipStreamWaitEvent(st, s->ev_parts_done, 0));
 	HIP_TRY(hipEventRecord(s->ev_pass[pass][1], st));
 	if (defer) {
 		// the number of queued rays stays on the device: a fixed grid of persistent waves drains the sub-queues
@@ -682,6 +742,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 	HIP_TRY(hipEventRecord(s->ev_pass[pass][3], st));
 	s->passes_timed = pass + 1;
 #undef HXR_KERNEL_ARGS
+#undef HXR_KERNEL_ARGS_OF
 	if (timed & TIME_END) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
 	return 0;
 }
@@ -738,6 +799,12 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	}
 	const bool usable = s->sched_history && memcmp(&key, &s->sched_key, sizeof key) == 0;
 	HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
+	// sample parts and single pixels go to the replicated-packet kernel where the scene's variant has one (words [10] count, [11] = 0, [12] ticket)
+	const bool use_parts = parts_kernel_for(s, L);
+	if (use_parts) {
+		rc = ensure((void**)&s->d_sched_items_r, &s->sched_items_r_cap, (size_t)capacity * sizeof(uint32_t));
+		if (rc) return rc;
+	}
 	if (usable) {
 		const int grid = (int)std::min<uint32_t>((n + 255u) / 256u, 1024u);
 		const int sum_grid = (int)std::min<uint32_t>((n + 255u) / 256u, 64u);   // one 64-bit atomic per wave on ONE word: 4096 of them cost 50 us, 256 cost 3
@@ -750,7 +817,8 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
 		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, defer_capacity(s, L.num_chunks, L.spp) == 0 && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr), n), frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
-		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2);
+		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2, use_parts ? s->d_sched_items_r : (uint32_t*)nullptr, (uint32_t*)s->d_sched_ctl + 10,
+		                   lanes_per_pixel <= 16 ? 1u : 0u);
 		HIP_TRY(hipGetLastError());
 	} else {
 		// No cost map yet.  Where can long chains of secondary rays be?  Only on the screen footprint of nodes whose shaders spawn them:
@@ -819,6 +887,19 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	// A frame without history: the chunks inside the screen rectangles -- where the long chains are, unsplit for want of measured costs -- run at the raised
 	// priority as well; once the list is through, the stragglers among them keep it against the ordinary packets (first frame of the headline 7.7 -> 7.15 ms)
 	if (!usable && !getenv("HXR_NO_FIRST_PRIORITY")) L.front_priority = 2;
+	if (use_parts && usable) {
+		s->parts_launch = L;                                   // same frame, same dispenser counters: once its list is through it takes ordinary packets
+		s->parts_launch.sched_items = s->d_sched_items_r;
+		s->parts_launch.sched_counts = (const uint32_t*)s->d_sched_ctl + 10;
+		s->parts_launch.sched_ticket = (uint32_t*)s->d_sched_ctl + 12;
+		s->parts_launch.front_priority = getenv("HXR_NO_FRONT_PRIORITY") ? 0 : 1;
+		s->parts_pending = true;
+		// ... and the main kernel takes from the same list (same ticket counter) once its own is through: a 1-spp pass lists thousands of single pixels
+		L.sched2_items = s->d_sched_items_r;
+		L.sched2_count = (const uint32_t*)s->d_sched_ctl + 10;
+		L.sched2_ticket = (uint32_t*)s->d_sched_ctl + 12;
+		L.sched2_early_above = (uint32_t)parts_grid(s) * (HXR_BLOCK / 64) * 4u;   // more than four items per replicating wave: everybody takes them from the start
+	}
 	s->sched_key = key;
 	s->sched_history = true;
 	s->sched_frame = true;
@@ -850,6 +931,8 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	HIP_TRY(hipMemsetAsync(s->d_work, 0, 1024 * sizeof(uint32_t), st));
 	if (want_counter_buffer) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
 	s->counters_valid = want_counter_buffer;
+	s->frame_counts = counters;
+	s->parts_pending = false;
 	s->timed = false;
 	s->aa_cost_aware = false;
 	s->sched_frame = false;
@@ -987,6 +1070,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	L3.sched_cost = nullptr;
 	L3.sched_flags = nullptr;
 	L3.sched_counts = nullptr;
+	L3.sched2_items = nullptr;
 	L3.front_priority = 0;
 	if (cost_aware) {   // the back of the flagged list, single pixels, first
 		L3.front_priority = getenv("HXR_NO_FRONT_PRIORITY") ? 0 : 2;   // ... and at the raised priority: they are this pass's long chains
@@ -997,6 +1081,10 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	}
 	L3.num_chunks = (tile_pixels + (uint32_t)L3.pixels_per_chunk - 1u) / (uint32_t)L3.pixels_per_chunk;
 	L3.work_counter = s->d_work + 256;
+	if (cost_aware && parts_kernel_for(s, L3)) {   // the heavy flagged pixels (the back of the list, one pixel = four taps per packet) go to the replicated-packet kernel
+		s->parts_launch = L3;   // same list, same ticket counter as the main kernel: whoever gets there first renders the pixel
+		s->parts_pending = true;
+	}
 	rc = launch_render(s, p, L3, counters, st, TIME_END, 1, 1.0f / 5);
 	if (rc) return rc;
 	if (!direct && tile_pixels) {
@@ -1437,6 +1525,7 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	for (int pass = 0; pass < 2; pass++)
 		for (int k = 0; k < 4; k++)
 			if (hipEventCreate(&s->ev_pass[pass][k]) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
+	if (pick_variant(s) == V_MESH && ensure_parts_stream(s)) return fail();   // (here, not inside a frame: creating a stream costs milliseconds)
 	// the preparation kernels above ran on the null stream; frames may be rendered on streams that do not wait for it
 	if (hipDeviceSynchronize() != hipSuccess) { set_err("scene preparation kernels failed: %s", hipGetErrorString(hipGetLastError())); return fail(); }
 	return s;
@@ -2002,6 +2091,10 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_sched_flags) (void)hipFree(s->d_sched_flags);
 	if (s->d_sched_items) (void)hipFree(s->d_sched_items);
 	if (s->d_sched_ctl) (void)hipFree(s->d_sched_ctl);
+	if (s->d_sched_items_r) (void)hipFree(s->d_sched_items_r);
+	if (s->parts_stream) (void)hipStreamDestroy(s->parts_stream);
+	if (s->ev_parts_go) (void)hipEventDestroy(s->ev_parts_go);
+	if (s->ev_parts_done) (void)hipEventDestroy(s->ev_parts_done);
 	if (s->d_sched_side) (void)hipFree(s->d_sched_side);
 	if (s->d_sched_part) (void)hipFree(s->d_sched_part);
 	if (s->d_queue) (void)hipFree(s->d_queue);

@@ -201,4 +201,14 @@ struct HxrLaunch {
 	// is what the launch waits for, and the arbiter lets it run at nearly the speed of a wave alone on its SIMD (8-way slowest rank 1.65 -> 1.51 ms); a whole
 	// frame loses 2.5 % of throughput by it and leaves it off.
 	int32_t front_priority;
+	int32_t no_replication;    // 1: HXR_F_REPL variants trace every packet one sample per lane (A/B aid: HXR_NO_REPLICATION)
+	// A second list of schedule items, taken once the first (sched_items) is through: the sample parts and single pixels that the replicating blocks
+	// (HXR_F_REPL instance, launched beside this kernel) take as THEIR first list -- whoever gets there first renders the item.  Null: none.
+	const uint32_t* sched2_items;
+	const uint32_t* sched2_count;    // device word: number of items
+	uint32_t* sched2_ticket;
+	// ... taken BEFORE the ordinary packets when it holds more items than this (a 1-spp pass lists thousands of single pixels: too many for the few
+	// replicating blocks), otherwise only once the ordinary packets are through (a shard of a multi-GPU frame lists a few hundred parts: the replicating
+	// blocks are through with them long before, and every one of them is traced replicated)
+	uint32_t sched2_early_above;
 };

@@ -65,13 +65,27 @@ enum : unsigned {
 	// launches a few packets deep (shards of a multi-GPU frame, first frames): there a packet's dependent chain is what the launch waits for and 28 % of a lone
 	// wave's chain is the wait for hot records (profiles/r04_chain_*.txt): slowest 8-way rank 1.51 -> 1.36 ms, the 3-waves instance 7.04 -> 6.72 ms per whole
 	// frame.  The throughput instance (four waves per SIMD) LOSES 6 % by it (128 spilled registers instead of 65) and stays without.
-	HXR_F_TOUCH = 8192u
+	HXR_F_TOUCH = 8192u,
+	// Replicated packets (round 4; uninstrumented latency instances only).  A packet with few rays -- the four samples of a sample-split part, the single pixel
+	// of a split chunk, the four taps of a flagged AA pixel -- is one long dependent chain on a wave that is mostly idle lanes.  Such a packet is traced with
+	// every ray held by R adjacent lanes (R = 16 for up to 4 rays, 4 for up to 16): identical state, identical control flow, so nothing else changes -- except
+	// in a kd leaf, where replica r of a ray tests triangles r, r + R, ... (its own vector loads of the hot records) and one prefix-minimum over the R
+	// lanes reproduces the sequential loop's accept rule exactly (leaf_query_replicated).  A leaf of up to 16 triangles is one round instead of 16 dependent
+	// iterations.
+	HXR_F_REPL = 16384u
 };
 #ifdef HXR_LEAF_TOUCH   // A/B aid: every kernel of the unit
 #define HXR_TOUCH_ALL true
 #else
 #define HXR_TOUCH_ALL false
 #endif
+#ifdef HXR_REPLICATE    // ... every uninstrumented kernel of the unit
+#define HXR_REPL_ALL true
+#else
+#define HXR_REPL_ALL false
+#endif
+template <bool COUNT, unsigned F>
+constexpr bool replicating = !COUNT && ((F & HXR_F_REPL) != 0 || HXR_REPL_ALL) && (F & (HXR_F_GI | HXR_F_DEFER | HXR_F_LANEWALK)) == 0;
 #ifndef HXR_LDS_RAY_SLOTS
 #define HXR_LDS_RAY_SLOTS 2   // 2 x 18 dwords x 256 lanes = 36 KB per block: three blocks per CU (3 waves per SIMD) fit the 160 KB; 4 slots (72 KB) allow two
 #endif
@@ -574,6 +588,7 @@ struct Stacks {
 	WaveStack* wave;
 	LaneStack lane;
 	uint32_t* pend;     // HXR_F_STACK1 variants: this wave's pending-ray slot, HXR_PEND_DWORDS rows x 64 lanes
+	int repl = 0;       // HXR_F_REPL: replicas per ray of the packet being traced (wave-uniform; 0 = one sample per lane), set per packet
 };
 #define HXR_PEND_DWORDS 18   // RayItem: o, d (6 dwords each), weight (3), depth, flags, key
 
@@ -654,6 +669,72 @@ HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, doub
 	return inside;
 }
 
+// value of the lane `n` below in the same row of 16 lanes (DPP row_shr:n); a lane without one keeps its own value
+template <int N>
+HXR_DEV double row_shr(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x110 + N, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x110 + N, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+// The leaf of a REPLICATED packet (HXR_F_REPL): every ray of the wave is held by R adjacent, aligned lanes with identical state.  Replica r tests triangle
+// r0 + r of every round of R triangles; the sequential loop's rule -- triangle i is taken iff it is valid and its distance is not above the running best,
+// which is the smallest distance of any valid triangle before it (or the best the ray came with) -- is an exclusive prefix minimum over the R lanes.  The ray
+// keeps the LAST taken triangle (ties go to the later one, like the loop's `!(gamma > best)`), and the leaf reports a hit iff any TAKEN triangle's point lies in
+// the leaf's box (Mesh::intersectKD ORs that over every take, src/mesh.cpp:228).  Same products, same reciprocal, same comparisons as triangle_decide: same
+// bits.  (A NaN distance, which the sequential loop would accept and keep, cannot occur: |Dcr| >= 1e-12 and finite operands.)
+template <int R>
+HXR_DEV unsigned long long leaf_query_replicated(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, unsigned long long mask, const Box& box, d3 o, d3 d, d3 nd, GeomHit& g)
+{
+	const int base = M.hot_first + first;
+	const int lane = threadIdx.x & 63, rep = lane & (R - 1), group0 = lane & ~(R - 1);
+	int hits = 0;
+	if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+		for (int r0 = 0; r0 < count; r0 += R) {   // wave-uniform
+			const int i = r0 + rep;
+			bool valid = false, inside = false;
+			double gamma = HXR_INF;
+			if (i < count) {
+				const HXR_GLOBAL HxrTriHot& hr = in_hbm(S.hot)[base + i];
+				bool facing = true;
+				if (M.backface_culling) facing = !(dot(d, ld3(in_hbm(M.tris)[in_hbm(S.hot_ids)[base + i]].gnormal)) > 0);   // src/mesh.cpp:180
+				double Dcr, ga, gb, gc;
+				tri_products(ld3(hr.N), ld3(hr.A), ld3(hr.AB), ld3(hr.AC), o, nd, Dcr, ga, gb, gc);
+				const double sgn = copysign(1.0, Dcr);
+				const double sa = ga * sgn, sb = gb * sgn, sc = gc * sgn;
+				const bool behind = (sa < 0) || (sb < 0) || (sc < 0);
+				if (facing && !(fabs(Dcr) < 1e-12) && !behind) {
+					const double rD = 1 / Dcr;
+					gamma = ga * rD;
+					const double l2 = gb * rD, l3 = gc * rD;
+					valid = !(l2 + l3 > 1);
+					inside = box_holds(box, o + d * gamma);
+				}
+			}
+			// inclusive prefix minimum of the valid distances over the group's lanes, then shifted by one: what the loop's running best would be at lane rep
+			double pm = valid ? gamma : HXR_INF;
+			{ const double t = row_shr<1>(pm); if (rep >= 1) pm = fmin(pm, t); }
+			if (R > 2) { const double t = row_shr<2>(pm); if (rep >= 2) pm = fmin(pm, t); }
+			if (R > 4) { const double t = row_shr<4>(pm); if (rep >= 4) pm = fmin(pm, t); }
+			if (R > 8) { const double t = row_shr<8>(pm); if (rep >= 8) pm = fmin(pm, t); }
+			double before = row_shr<1>(pm);
+			if (rep == 0) before = HXR_INF;
+			const bool taken = valid && !(gamma > fmin(g.t, before));
+			const unsigned long long bt = hxr_ballot(taken), bi = hxr_ballot(taken && inside);
+			const uint32_t gt = (uint32_t)(bt >> group0) & ((1u << R) - 1u), gi = (uint32_t)(bi >> group0) & ((1u << R) - 1u);
+			const int last = 31 - __builtin_clz(gt | 1u);               // highest taken replica of this ray (0 when none: masked below)
+			const double best = __shfl(gamma, group0 + last, 64);
+			if (gt) {
+				g.t = best;
+				g.tri = base + r0 + last;
+			}
+			hits |= gi != 0 ? 1 : 0;
+		}
+	}
+	return hxr_ballot(hits != 0);
+}
+
 // Leaf of Mesh::intersectKD (src/mesh.cpp:223-232): every triangle is tested against the running
 // best distance; a hit counts for THIS leaf only if its point lies in the leaf's box.
 // Mesh::intersectTriangle (src/mesh.cpp:178-195) accepts iff  0 <= gamma <= best, 0 <= l2 <= 1, 0 <= l3 <= 1,
@@ -664,11 +745,19 @@ HXR_DEV bool triangle_decide(bool facing, double Dcr, double ga, double gb, doub
 // and stay in SGPRs, so a triangle costs the lanes no vector registers.  The triangle NUMBER of a record (hot_ids) is not read
 // here: a hit remembers its record, surface_of() looks the number up for the one hit a ray keeps.
 // `mask`: the lanes taking part (wave-uniform); returns the lanes that found a hit inside the leaf's box.
-template <bool COUNT, bool TOUCH>
+template <bool COUNT, bool TOUCH, int REPL>   // REPL: 0 never, 1 the packets that say so (`repl`), 2 every packet of the kernel (a kernel that only takes replicated packets)
 HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M, int first, int count, unsigned long long mask, const Box& box, d3 o, d3 d, d3 nd,
-                                      GeomHit& g, Tally<COUNT>& tl)
+                                      GeomHit& g, Tally<COUNT>& tl, int repl)
 {
 	tl.template lap<PH_MESH>();
+	if constexpr (REPL != 0) {
+		if (repl) {   // (wave-uniform) a replicated packet: the lane-parallel leaf
+			const unsigned long long f = repl == 16 ? leaf_query_replicated<16>(S, M, first, count, mask, box, o, d, nd, g) : leaf_query_replicated<4>(S, M, first, count, mask, box, o, d, nd, g);
+			tl.template lap<PH_LEAF>();
+			return f;
+		}
+	}
+	if constexpr (REPL != 2) {
 #if defined(HXR_LEAF_STATS) || defined(HXR_LEAF_HIST)   // developer aids: how many lanes take part in a leaf visit (would testing ray x triangle pairs in parallel pay?)
 	{
 		const int k = __popcll(mask), me_ = threadIdx.x & 63;
@@ -730,6 +819,7 @@ HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M,
 	const unsigned long long found = hxr_ballot(hits != 0);
 	tl.template lap<PH_LEAF>();
 	return found;
+	} else return 0ull;
 }
 
 // BBox::testIntersect (slab form: box_hit) of BOTH children of a kd node for one ray.  The children's boxes are the node's with one
@@ -794,7 +884,7 @@ HXR_DEV void kd_children_hit(const Box& b, int axis, double split, d3 o, d3 inv,
 // its best hit.  The work counters are per lane and equal the reference's per-ray counts: a lane's test of its NEAR child is
 // counted when the node is entered, that of its FAR child when that child's turn comes and the lane is still searching (`due`
 // masks, instrumented builds only) -- exactly when the reference makes it.
-template <bool COUNT, bool TOUCH>
+template <bool COUNT, bool TOUCH, int REPL>
 HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, const Stacks& st, Tally<COUNT>& tl)
 {
 	tl.template lap<PH_QUERY>();
@@ -810,7 +900,7 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	if (!alive) { tl.template lap<PH_MESH>(); return false; }
 	if (!M.has_kd) {   // brute force over every triangle (src/mesh.cpp:253-261)
 		Box everything{mk3(-HXR_INF, -HXR_INF, -HXR_INF), mk3(HXR_INF, HXR_INF, HXR_INF)};
-		leaf_query<COUNT, TOUCH>(S, M, 0, M.num_triangles, alive, everything, o, d, nd, g, tl);
+		leaf_query<COUNT, TOUCH, REPL>(S, M, 0, M.num_triangles, alive, everything, o, d, nd, g, tl, st.repl);
 		tl.template lap<PH_MESH>();
 		return in_root && g.t < HXR_INF;
 	}
@@ -830,7 +920,7 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) atomicAdd(S.dev_stats + 5, 1ull);   // walk steps
 #endif
 		if (axis == HXR_KD_LEAF) {
-			const unsigned long long here = leaf_query<COUNT, TOUCH>(S, M, R.first, ac >> 2, mask, cb, o, d, nd, g, tl);
+			const unsigned long long here = leaf_query<COUNT, TOUCH, REPL>(S, M, R.first, ac >> 2, mask, cb, o, d, nd, g, tl, st.repl);
 			found |= here;
 			alive &= ~here;
 		} else {
@@ -1163,7 +1253,7 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 		case HXR_GEOM_MESH:
 			if constexpr ((F & HXR_F_MESH) != 0) {
 				if constexpr ((F & HXR_F_LANEWALK) != 0) return mesh_query_lane<COUNT>(S, S.meshes[N.ref], ol, dl, g, st.lane, tl);
-				else return mesh_query<COUNT, (F & HXR_F_TOUCH) != 0 || HXR_TOUCH_ALL>(S, S.meshes[N.ref], ol, dl, g, st, tl);
+				else return mesh_query<COUNT, (F & HXR_F_TOUCH) != 0 || HXR_TOUCH_ALL, (replicating<COUNT, F> ? 1 : 0)>(S, S.meshes[N.ref], ol, dl, g, st, tl);
 			}
 			return false;
 		case HXR_GEOM_HEIGHTFIELD:
@@ -1996,6 +2086,9 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	const bool scheduled = P.sched_counts != nullptr && mode_ != 2;   // pass 3 only takes a list of single pixels (see the AA host path)
 	const uint32_t listed_a = P.sched_counts ? P.sched_counts[0] : 0u, listed_b = P.sched_counts ? P.sched_counts[1] : 0u;
 	bool listed_left = listed_a + listed_b > 0;
+	const uint32_t listed2 = P.sched2_items ? *P.sched2_count : 0u;   // the second list (HxrLaunch::sched2_items)
+	bool listed2_left = listed2 > 0;
+	bool listed2_now = listed2 > P.sched2_early_above;               // ... before the ordinary packets, or after them
 	for (;;) {
 		if (P.cancel) {   // the host raised the cancel word (hxr_render): no further packets; every wave leaves through the common exit below.
 			// The word lives in pinned HOST memory mapped into the device (a copy engine or blit kernel could starve behind the persistent
@@ -2014,6 +2107,13 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			else if (t - listed_a < listed_b) single_pixel = P.sched_items[P.sched_capacity - 1u - (t - listed_a)];
 			else listed_left = false;
 		}
+		if (single_pixel == 0xffffffffu && listed2_left && listed2_now) {
+			uint32_t t = 0;
+			if (lane == 0) t = atomicAdd(P.sched2_ticket, 1u);
+			t = __builtin_amdgcn_readfirstlane(t);
+			if (t < listed2) { single_pixel = P.sched2_items[t]; from_front = true; }
+			else listed2_left = false;
+		}
 		if (single_pixel == 0xffffffffu) {
 			if (batch_pos >= batch_end) {
 				bool got = false;
@@ -2031,6 +2131,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 					shard = (shard + 1) & (HXR_SHARDS - 1);
 					shards_done++;
 				}
+				if (!got && listed2_left && !listed2_now) { listed2_now = true; continue; }   // the ordinary packets are through: what is left of the second list
 				if (!got) break;
 			}
 			if (scheduled && P.sched_flags[batch_pos]) { batch_pos++; continue; }   // its pixels were handed out from the list
@@ -2114,7 +2215,59 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			}
 		}
 		f3 sum = mkf(0, 0, 0);
-		if (live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group)) {
+		int repl_shift = 0;   // HXR_F_REPL: log2 of the replicas per ray of this packet (0: one sample per lane)
+		if constexpr (replicating<COUNT, F>) {
+			// which sample this lane traces: its own (lane = pixel slot x samples per pixel + sample) -- or, in a replicated packet, the sample of the group of
+			// R lanes it belongs to
+			int tsub = sub, tx = x, ty = y;
+			bool tlive = live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group);
+			Stacks rstacks = stacks;
+			const int rays = part ? HXR_PART_LANES : lanes_per_pixel;   // rays of a one-pixel packet
+			if (rounds == 1 && (part || single) && mode_ != 3 && rays <= 16 && !P.no_replication) {
+				repl_shift = rays <= 4 ? 4 : 2;
+				rstacks.repl = 1 << repl_shift;
+				const int ray = lane >> repl_shift;
+				tsub = (part ? (int)part_group * HXR_PART_LANES : 0) + ray;
+				tx = __builtin_amdgcn_readlane(x, 0);      // lane 0 is the first lane of the packet's one pixel
+				ty = __builtin_amdgcn_readlane(y, 0);
+				tlive = (hxr_ballot(live) & 1ull) != 0 && ray < rays && tsub < spp;
+			}
+			if (tlive) {
+				const Stacks& stacks = rstacks;
+				const int x = tx, y = ty, sub = tsub;   // (shadow the packet's own: the loop below is written in their terms)
+				RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
+				for (int rd = 0; rd < rounds; rd++) {
+					int s = sub + rd * 64;
+					if (s >= spp) break;
+					double sx = x, sy = y;
+					if (mode_ == 1) {          // renderWithMonteCarlo: x + randDouble(), y + randDouble() (src/main.cpp:373-375)
+						rc.sample = (uint32_t)s;
+						double jx, jy;
+						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_PIXEL_JITTER), jx, jy);
+						sx = x + jx;
+						sy = y + jy;
+					} else if (mode_ == 3) {   // coarseRender: x + randDouble() * BLK_SIZE, y + randDouble() * BLK_SIZE (src/main.cpp:396)
+						rc.sample = (uint32_t)s;
+						double jx, jy;
+						hxr_uniform2(hxr_philox(rc.seed, rc.pixel, rc.sample, 0, HXR_DIM_PREPASS), jx, jy);
+						sx = x + jx * 24;
+						sy = y + jy * 24;
+					} else if (mode_ == 2) {   // pass 3 taps 1..4 of AA_KERNEL; `x + 0.6f` is float arithmetic (src/main.cpp:255-261,336)
+						const float kx[4] = {0.6f, 0.3f, 0.0f, 0.6f}, ky[4] = {0.0f, 0.3f, 0.6f, 0.6f};
+						rc.sample = (uint32_t)(s + 1);
+						sx = (double)((float)x + kx[s]);
+						sy = (double)((float)y + ky[s]);
+					}
+					f3 c = trace_sample<COUNT, F>(S, P.W, P.H, sx, sy, rc, stacks, tl, dq);
+					sum = (rd == 0) ? c : sum + c;
+				}
+			}
+			if (repl_shift) {   // (wave-uniform) hand every sample's colour to the lane that owns it in the ordinary layout: replica 0 of its group
+				const int src = ((sub - (part ? (int)part_group * HXR_PART_LANES : 0)) << repl_shift) & 63;
+				sum = mkf(__shfl(sum.x, src, 64), __shfl(sum.y, src, 64), __shfl(sum.z, src, 64));
+				if (!(live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group))) sum = mkf(0, 0, 0);   // lanes that own no sample of this packet
+			}
+		} else if (live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group)) {
 			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
 			for (int rd = 0; rd < rounds; rd++) {
 				int s = sub + rd * 64;
@@ -2366,10 +2519,16 @@ __global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t
 // in a quarter of the time); chunks above `first_x` times the mean are listed whole, from the back (expensive but coherent:
 // only started early).  `items` has one entry per pixel, so the two lists cannot meet.  `cost` is cleared for the frame
 // about to be rendered.
+// `items_r` / `count_r` (may be null): a second list for the items that the replicating blocks take first (HXR_F_REPL): sample parts always, single pixels
+// when `route_pixels` (a pixel's samples fit 16 lanes).  They then do not appear in `items`.
 __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc, uint32_t num_pixels, const unsigned long long* total, uint32_t split_x,
                                        uint32_t first_x, uint32_t resident_waves, uint32_t frame_div, uint32_t part_groups, uint8_t* flags, uint32_t* items, uint32_t capacity,
-                                       uint32_t* part_pixels, uint32_t* counts)
+                                       uint32_t* part_pixels, uint32_t* counts, uint32_t* items_r, uint32_t* count_r, uint32_t route_pixels)
 {
+	uint32_t* part_items = items_r ? items_r : items;
+	uint32_t* part_count = items_r ? count_r : counts + 0;
+	uint32_t* pixel_items = items_r && route_pixels ? items_r : items;
+	uint32_t* pixel_count = items_r && route_pixels ? count_r : counts + 0;
 	const unsigned long long mean = *total / (n ? n : 1u);
 	// a packet is worth splitting when it is long against the frame itself: as long as what one wave gets through when the work
 	// is spread perfectly (a shard of an 8-GPU frame is eight times shorter than the whole frame, its limit eight times lower)
@@ -2386,13 +2545,13 @@ __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc,
 					const uint32_t ps = atomicAdd(counts + 2, 1u);
 					if (ps < HXR_PART_SLOTS) {
 						part_pixels[ps] = first + j;
-						const uint32_t at = atomicAdd(counts + 0, part_groups);
-						for (uint32_t g = 0; g < part_groups; g++) items[at + g] = HXR_SCHED_PART | (g << 22) | ps;
-					} else items[atomicAdd(counts + 0, 1u)] = first + j;
+						const uint32_t at = atomicAdd(part_count, part_groups);
+						for (uint32_t g = 0; g < part_groups; g++) part_items[at + g] = HXR_SCHED_PART | (g << 22) | ps;
+					} else pixel_items[atomicAdd(pixel_count, 1u)] = first + j;
 				}
 			} else if (c > split_above && ppc > 1) {
-				const uint32_t at = atomicAdd(counts + 0, cnt);
-				for (uint32_t j = 0; j < cnt; j++) items[at + j] = first + j;
+				const uint32_t at = atomicAdd(pixel_count, cnt);
+				for (uint32_t j = 0; j < cnt; j++) pixel_items[at + j] = first + j;
 			} else if (c > split_above / HXR_SCHED_URGENT_DIV) {
 				// long against the frame, though not long enough to split: at the FRONT, behind the split ones -- the back list is thousands
 				// of chunks in the order their atomics landed, two rounds of the resident waves deep, and a packet of a millisecond that

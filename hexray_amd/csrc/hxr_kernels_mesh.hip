@@ -10,7 +10,8 @@
 #include "hxr_variants.h"
 
 HXR_VARIANTS_MESH_DEFER(HXR_INSTANTIATE)
-HXR_VARIANTS_MESH_INPLACE(HXR_INSTANTIATE_LAUNCH_MODE)   // their Monte-Carlo instances -- the headline kernel -- live in hxr_kernels_mesh_mc.hip
+HXR_VARIANTS_MESH_INPLACE(HXR_INSTANTIATE_LAUNCH_MODE)
+HXR_VARIANTS_MESH_PARTS(HXR_INSTANTIATE_LAUNCH_MODE)   // the replicated-packet kernel of 1-spp and adaptive-AA passes   // their Monte-Carlo instances -- the headline kernel -- live in hxr_kernels_mesh_mc.hip
 HXR_VARIANTS_MESH_STACK1(HXR_INSTANTIATE)
 HXR_VARIANTS_MESH_INPLACE(HXR_INSTANTIATE_CONTINUE)
 HXR_VARIANTS_MESH_LANEWALK(HXR_INSTANTIATE_CONTINUE)

@@ -10,3 +10,4 @@
 #include "hxr_variants.h"
 
 HXR_VARIANTS_MESH_INPLACE_MC(HXR_INSTANTIATE_MONTE_CARLO)
+HXR_VARIANTS_MESH_PARTS(HXR_INSTANTIATE_MONTE_CARLO)

@@ -39,6 +39,11 @@
 	X(false, (HXR_F_MESH | HXR_F_TOUCH), HXR_MESH_WAVES)   \
 	X(false, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES) \
 	X(true, (HXR_F_MESH | HXR_F_REFRACT), HXR_MESH_WAVES)
+// ... and the instances that trace the schedule's sample parts and single pixels as REPLICATED packets with the lane-parallel leaf (HXR_F_REPL; round 4).  A few
+// blocks of them are launched beside the kernel that renders the rest of the frame (hxr_api.hip, launch_render): they drain the list of such packets first and
+// then take ordinary packets like everybody else.  In EVERY wave the mere presence of that leaf costs what it gains (8-way slowest rank 1.40 -> 1.61 ms with the
+// code compiled in and unused, 1.37 used), in an eighth of the waves it does not.
+#define HXR_VARIANTS_MESH_PARTS(X) X(false, (HXR_F_MESH | HXR_F_TOUCH | HXR_F_REPL), HXR_MESH_WAVES)
 // ... with at most one secondary ray pending per lane (no Layered shader of the scene has two Reflection / Refraction layers): the
 // default for mesh scenes -- the per-lane ray stack leaves scratch memory
 #define HXR_VARIANTS_MESH_STACK1(X)                              \

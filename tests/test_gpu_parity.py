@@ -338,6 +338,44 @@ def test_adaptive_schedule_does_not_change_the_frame(gpu):
             assert c[k] == oc[k], (k, c[k], oc[k])
 
 
+def test_replicated_packets_and_their_blocks_render_the_same_bits(gpu, monkeypatch):
+    """Round 4.  Launches a few packets deep run the latency instances: the next-record prefetch in the leaf loop (HXR_F_TOUCH), issue priority for the listed
+    packets, and -- beside the main kernel, on a stream of their own -- a few blocks of the replicating instance (HXR_F_REPL), which trace sample parts and
+    single pixels with every ray held by 4 or 16 lanes and test a leaf's triangles in parallel (leaf_query_replicated).  None of it may change a bit: the
+    same frames with the replication switched off inside those blocks, without the blocks, and without the priorities; scheduled frames (the lists exist from
+    the second frame on) and, for the Monte-Carlo case, an 8-way shard."""
+    cases = [(hx.overlay_text(640, 360, dof=True, num_samples=16), dict()),                       # parts of four samples, single pixels of sixteen lanes
+             (hx.overlay_text(640, 360, dof=True, num_samples=8), dict()),                        # two parts per pixel, eight-lane pixels (four replicas)
+             (hx.overlay_text(960, 540, want_aa=False), dict(mode=hx.MODE_SINGLE)),                # single pixels of one ray
+             (hx.overlay_text(960, 540), dict(mode=hx.MODE_ADAPTIVE_AA))]                          # + the four taps of the heavy flagged pixels
+    for ov, fp in cases:
+        hs = hx.HostScene(scene_path("meshes.hexray"), ov)
+        plain = hx.DeviceScene(hs, adaptive_schedule=False).render(hx.frame_params(**fp))
+        for env in ({}, {"HXR_NO_REPLICATION": "1"}, {"HXR_NO_PARTS_KERNEL": "1"}, {"HXR_NO_FRONT_PRIORITY": "1", "HXR_NO_FIRST_PRIORITY": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ds = hx.DeviceScene(hs)
+            for _ in range(3):
+                assert np.array_equal(ds.render(hx.frame_params(**fp)), plain), (fp, env)
+            if not fp:   # one rank's tiles of an 8-way frame (three frames: first, scheduled, scheduled)
+                import torch
+                from hexray_amd.distributed import padded_tiles_per_rank
+                W, H, T, world, rank = hs.settings.frame_width, hs.settings.frame_height, 8, 8, 3
+                slots = padded_tiles_per_rank(W, H, T, world)
+                p = hx.frame_params(tile_size=T, shard_rank=rank, shard_count=world, layout=hx.LAYOUT_TILES)
+                buf = torch.zeros(slots * T * T * 3, dtype=torch.float32, device="cuda")
+                for _ in range(3):
+                    buf.zero_()
+                    ds.render_device(p, buf.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    tiles = buf.cpu().numpy().reshape(slots, T, T, 3)
+                    for i, (x0, y0, x1, y1) in enumerate(ds.shard_tiles(p)):
+                        assert np.array_equal(tiles[i, :y1 - y0, :x1 - x0], plain[y0:y1, x0:x1]), (env, i)
+            ds.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_first_frame_schedule_lists_the_same_chunks_for_every_tile_size(gpu):
     """A frame without history starts with the chunks inside the screen rectangles of the nodes that spawn secondary rays
     (hxr_sched_rects_kernel).  Which chunks those are does not depend on how the frame is tiled: a chunk is 64 / spp consecutive pixel

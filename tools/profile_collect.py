@@ -32,4 +32,12 @@ comp[workload] = {
     "profile": f"profiles/{tag}_pmc_summary.json",
 }
 json.dump(comp, open(cpath, "w"), indent=1)
+# what bench.py falls back to when it cannot collect the counters itself (live rocprofv3 passes): the same counters, with the id of the kernel sources they were
+# taken on -- bench.py uses the file only when that id is the checkout's (bench.kernel_build_id)
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+need = [c for _, cs in bench.PMC_PASSES for c in cs]
+if all(c in s for c in need):
+    json.dump({"workload": workload, "kernel_build": bench.kernel_build_id(), "profile": f"profiles/{tag}_pmc_summary.json", "counters": {c: s[c] for c in need}},
+              open(os.path.join(dst, "pmc_live_%s.json" % workload), "w"), indent=1)
 print(json.dumps(comp[workload], indent=1))
