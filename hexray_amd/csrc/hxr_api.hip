@@ -474,10 +474,10 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 	L.no_replication = getenv("HXR_NO_REPLICATION") ? 1 : 0;
 }
 
-int parts_grid(const hxr_scene* s)   // blocks of the replicating instance launched beside the main kernel: an eighth of the machine at three waves per SIMD
+int parts_grid(const hxr_scene* s)   // blocks of the replicating instance launched beside the main kernel: three sixteenths of the machine at three waves per SIMD
 {
 	if (const char* e = getenv("HXR_PARTS_GRID")) return std::max(1, atoi(e));   // developer aid
-	return std::max(1, s->num_cu * HXR_MESH_WAVES / 8);
+	return std::max(1, s->num_cu * HXR_MESH_WAVES * 3 / 16);   // slowest 8-way rank: 1.84 ms at 48 blocks, 1.24-1.34 at 96, 1.22 at 144, 1.20-1.21 at 192 (sum of ranks 9.5 / 9.5 / 9.6)
 }
 
 int grid_for(const hxr_scene* s, uint32_t chunks)
@@ -1048,7 +1048,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
 			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
 		}
-		uint32_t heavy_x = 16;   // frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list)
+		uint32_t heavy_x = 4;    // round 1, frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list); round 4, with the heavy pixels replicated: 4 / 8 / 16 / 32: 1.75 / 1.82 / 1.83 / 1.82
 		if (const char* e = getenv("HXR_AA_HEAVY_X")) heavy_x = (uint32_t)atoi(e);   // developer aid
 		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * 8u);
 		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512),
@@ -1444,6 +1444,9 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 			o.cull_hi[0] = r * r;
 			o.cull_hi[1] = o.cull_hi[2] = 0;
 			o.cullable = (ok && std::isfinite(o.cull_hi[0])) ? 1 : 0;
+			// an untransformed mesh node: nothing is saved by the sphere test -- no matrix products to skip, and Mesh::intersect's own root-box test is as cheap and
+			// leaves the wave just the same when no lane reaches the box (cornell16 46.95 -> 46.28 ms; HXR_CULL_IDENTITY_MESH=1: A/B aid)
+			if (o.identity && g.type == HXR_GEOM_MESH && !getenv("HXR_CULL_IDENTITY_MESH")) o.cullable = 0;
 		}
 		{   // does a hit of this node spawn secondary rays?  (first-frame schedule, prepare_schedule)
 			int rays = 0, pending = 1;

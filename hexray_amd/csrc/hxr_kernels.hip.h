@@ -2268,6 +2268,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 				if (!(live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group))) sum = mkf(0, 0, 0);   // lanes that own no sample of this packet
 			}
 		} else if (live && (!part || (uint32_t)sub / HXR_PART_LANES == part_group)) {
+			// (the same loop as above, spelled out a second time: shared through a lambda it costs the headline kernel 33 more spilled scalar registers)
 			RngCtx rc{P.seed, (uint32_t)(y * P.W + x), 0u};
 			for (int rd = 0; rd < rounds; rd++) {
 				int s = sub + rd * 64;
@@ -2662,12 +2663,17 @@ __global__ __launch_bounds__(64) void hxr_autofocus_kernel(
 // `cost` (may be null): what the 64-pixel chunks of pass 1 took; flagged pixels of chunks above `heavy_x` times the mean go to the BACK of
 // the list (`heavy_count` of them), to be traced first and one pixel per packet by pass 3 -- the flagged set is small and made
 // of the most expensive pixels of the frame, so a few 32-lane packets of them would otherwise decide when pass 3 ends.
+#define HXR_DETECT_LDS 2048   // flagged pixels a block collects in LDS before it falls back to one atomic per pixel
 __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, const float* __restrict__ frame, size_t stride, int32_t* list,
                                                                    int32_t* count, const uint32_t* __restrict__ cost, const unsigned long long* total,
                                                                    uint32_t cost_chunks, uint32_t* heavy_count, uint32_t capacity, uint32_t heavy_x)
 {
 	const unsigned long long heavy_above = cost ? (unsigned long long)heavy_x * (*total / (cost_chunks ? cost_chunks : 1u)) : ~0ull;
 	uint32_t tile_pixels = (uint32_t)P.num_shard_tiles * (uint32_t)(P.tile_size * P.tile_size);
+	__shared__ int32_t s_list[2][HXR_DETECT_LDS];   // this block's flagged pixels: [0] ordinary, [1] of heavy chunks
+	__shared__ uint32_t s_n[2], s_base[2];
+	if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+	__syncthreads();
 	// An unsharded frame is walked ROW-MAJOR (round 4): a wave then reads three contiguous 768-byte runs of the frame instead of an 8x8 block's 24 short rows
 	// (155 -> ~40 us at 1920x1080: the pass between the two render passes of an adaptive-AA frame); the pixel's number in shard order, which indexes the
 	// pass-1 cost map, is formed from (x, y).  Shards keep the tile order: their pixels are not a rectangle.  The ORDER of the flagged list differs between
@@ -2707,16 +2713,21 @@ __global__ __launch_bounds__(HXR_BLOCK) void hxr_detect_aa_kernel(HxrLaunch P, c
 			need = worst > 0.075f;
 		}
 		const bool heavy = need && cost && (unsigned long long)cost[q >> 6] > heavy_above;   // pass-1 chunks are 64 consecutive pixel numbers
-		unsigned long long mask = hxr_ballot(need && !heavy), hmask = hxr_ballot(heavy);
-		int lane = threadIdx.x & 63;
-		int base = 0, hbase = 0;
-		if (lane == 0 && mask) base = atomicAdd(count, __popcll(mask));
-		if (lane == 0 && hmask) hbase = (int)atomicAdd(heavy_count, (uint32_t)__popcll(hmask));
-		base = __shfl(base, 0, 64);
-		hbase = __shfl(hbase, 0, 64);
-		if (need && !heavy) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = y * P.W + x;
-		if (heavy) list[capacity - 1u - (uint32_t)(hbase + __popcll(hmask & ((1ull << lane) - 1ull)))] = y * P.W + x;
+		// collected per BLOCK in LDS (round 4): one global atomic per block and list instead of one per wave -- a single counter takes ~88 atomics per
+		// microsecond, and half the waves of a 1080p frame hold a flagged pixel
+		if (need && !heavy) { const uint32_t at = atomicAdd(&s_n[0], 1u); if (at < HXR_DETECT_LDS) s_list[0][at] = y * P.W + x; else list[atomicAdd(count, 1)] = y * P.W + x; }
+		if (heavy) { const uint32_t at = atomicAdd(&s_n[1], 1u); if (at < HXR_DETECT_LDS) s_list[1][at] = y * P.W + x; else list[capacity - 1u - atomicAdd(heavy_count, 1u)] = y * P.W + x; }
 	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const uint32_t n0 = min(s_n[0], (uint32_t)HXR_DETECT_LDS), n1 = min(s_n[1], (uint32_t)HXR_DETECT_LDS);
+		s_base[0] = n0 ? (uint32_t)atomicAdd(count, (int)n0) : 0u;
+		s_base[1] = n1 ? atomicAdd(heavy_count, n1) : 0u;
+	}
+	__syncthreads();
+	const uint32_t n0 = min(s_n[0], (uint32_t)HXR_DETECT_LDS), n1 = min(s_n[1], (uint32_t)HXR_DETECT_LDS);
+	for (uint32_t k = threadIdx.x; k < n0; k += blockDim.x) list[s_base[0] + k] = s_list[0][k];
+	for (uint32_t k = threadIdx.x; k < n1; k += blockDim.x) list[capacity - 1u - (s_base[1] + k)] = s_list[1][k];
 }
 
 // own tiles of a row-major scratch frame -> the caller's buffer: tile-major (`as_tiles`) or row-major with `dst_stride` bytes per row

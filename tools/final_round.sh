@@ -18,4 +18,11 @@ timeout -k 10 300 python3 tools/sah_build_times.py > $out/sah_build_times.txt 2>
 timeout -k 10 120 hexray_amd/bin/hexray data/simple.hexray --interactive 300 > $out/interactive_simple.txt 2>&1
 timeout -k 10 120 hexray_amd/bin/hexray data/simple.hexray --interactive 300 --fovea 75 >> $out/interactive_simple.txt 2>&1
 timeout -k 10 120 hexray_amd/bin/hexray data/meshes.hexray --width 1920 --height 1080 --dof on --spp 16 --frames 5 --devices 0,0 >> $out/interactive_simple.txt 2>&1
-tail -2 $out/bench.json | cut -c1-600; tail -8 $out/interactive_simple.txt
+# round 4: the lone chain's split (needs tools/build_alt.sh chain4 -DHXR_PHASE_TIMERS -DHXR_PHASE_SET=4 beforehand), the adaptive-AA frame's per-kernel timeline,
+# and the A/B lines of the latency measures (priorities, replicating blocks) on the headline's three figures
+[ -f hexray_amd/lib/libhexray_hip_chain4.so ] && bash tools/r4_chain.sh $tag > $out/chain.log 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/$out/aa_trace -- python3 $OLDPWD/tools/run_frame.py meshes_aa 6 > $OLDPWD/$out/aa_trace.log 2>&1)
+find $out/aa_trace -name "*kernel_trace.csv" -exec cp {} $out/aa_kernel_trace.csv \; ; rm -rf $out/aa_trace
+python3 tools/aa_timeline.py $out/aa_kernel_trace.csv > $out/aa_timeline.txt 2>&1
+bash tools/r4_ab2.sh $tag "-|A=1" "-|HXR_NO_PARTS_KERNEL=1" "-|HXR_NO_PARTS_KERNEL=1 HXR_NO_FRONT_PRIORITY=1 HXR_NO_FIRST_PRIORITY=1" > /dev/null 2>&1
+tail -2 $out/bench.json | cut -c1-600; tail -8 $out/interactive_simple.txt; cat $out/ab.txt
