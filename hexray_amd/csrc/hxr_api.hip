@@ -566,7 +566,7 @@ bool parts_kernel_for(const hxr_scene* s, const HxrLaunch& L)
 	if (defer_capacity(s, L.num_chunks, L.spp) != 0 || (s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr)) return false;
 	// launches that run the three-waves (latency) instances: 1-spp and AA passes, Monte-Carlo launches a few packets deep -- the replicating instance is one of them
 	// and shares the SIMDs with the others on equal terms; a whole Monte-Carlo frame (four waves of 128 registers) does not take it
-	if (L.mode == 1 && mesh_mc_waves(s, L.num_chunks) != HXR_MESH_WAVES) return false;   // (tried: 6.45 -> 8.2 ... 9.5 ms per whole frame)
+	if (L.mode == 1 && mesh_mc_waves(s, L.num_chunks) != HXR_MESH_WAVES) return false;   // (tried: with the 168-register instance 6.45 -> 8.2 ... 9.5 ms per whole frame, with a 128-register one 6.68 -> 6.75 ... 6.97)
 	return L.mode == 0 || L.mode == 1 || L.mode == 2;
 }
 

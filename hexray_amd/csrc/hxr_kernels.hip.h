@@ -929,6 +929,14 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			const HxrKdPair kids = *(const HxrKdPair*)(kd + left);   // in flight while the children's boxes are being tested
 			bool pl, pr;
 			kd_children_hit(cb, axis, split, o, inv, origin_in_root, mask, pl, pr);
+			if constexpr (COUNT) {   // instrumented builds: the children's slab answers against BBox::testIntersect taken literally, for the lanes of the visit (hxr_counters::box_test_mismatch)
+				if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+					Box lb = cb, rb = cb;
+					if (axis == 0) { lb.hi.x = split; rb.lo.x = split; } else if (axis == 1) { lb.hi.y = split; rb.lo.y = split; } else { lb.hi.z = split; rb.lo.z = split; }
+					if (box_hit_literal(lb, o, d, inv) != pl) tl.add(HC_BOXMISMATCH);
+					if (box_hit_literal(rb, o, d, inv) != pr) tl.add(HC_BOXMISMATCH);
+				}
+			}
 			// lanes of the visit that reach the left / right child, and those whose near child is the right one
 			const unsigned long long ml = hxr_ballot(pl) & mask, mr = hxr_ballot(pr) & mask, rm = hxr_ballot(comp(o, axis) > split) & mask;
 			if (COUNT && __builtin_amdgcn_inverse_ballot_w64(mask)) tl.add(HC_BBOX);   // the near child's test; the far child's is counted when its turn comes
