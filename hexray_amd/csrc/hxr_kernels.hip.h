@@ -74,7 +74,7 @@ enum : unsigned {
 	// iterations.
 	HXR_F_REPL = 16384u
 };
-#ifdef HXR_LEAF_TOUCH   // A/B aid: every kernel of the unit
+#ifdef HXR_LEAF_TOUCH   // every Whitted kernel of the unit (the path tracers lose by it)
 #define HXR_TOUCH_ALL true
 #else
 #define HXR_TOUCH_ALL false
@@ -1261,7 +1261,7 @@ HXR_DEV bool geometry_query(const HxrSceneDev& S, const HxrNodeDev& N, d3 ol, d3
 		case HXR_GEOM_MESH:
 			if constexpr ((F & HXR_F_MESH) != 0) {
 				if constexpr ((F & HXR_F_LANEWALK) != 0) return mesh_query_lane<COUNT>(S, S.meshes[N.ref], ol, dl, g, st.lane, tl);
-				else return mesh_query<COUNT, (F & HXR_F_TOUCH) != 0 || HXR_TOUCH_ALL, (replicating<COUNT, F> ? 1 : 0)>(S, S.meshes[N.ref], ol, dl, g, st, tl);
+				else return mesh_query<COUNT, (F & HXR_F_TOUCH) != 0 || (HXR_TOUCH_ALL && (F & HXR_F_GI) == 0), (replicating<COUNT, F> ? 1 : 0)>(S, S.meshes[N.ref], ol, dl, g, st, tl);
 			}
 			return false;
 		case HXR_GEOM_HEIGHTFIELD:
