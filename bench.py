@@ -162,6 +162,10 @@ def live_pmc(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # never under another profiler: a counter pass started from a traced process would inherit its tool library and combine tracing with --pmc
+    profiler_env = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTX", "ROCPROFILER"))]
+    if profiler_env or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler (%s): no nested counter passes" % ", ".join(profiler_env[:3] or ["LD_PRELOAD"])
     out = {}
     work = tempfile.mkdtemp(prefix="hxr_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -171,7 +175,7 @@ def live_pmc(args):
             cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                                                       "--workload", args.workload, "--accel", args.accel]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=90)
             except subprocess.TimeoutExpired:
                 return None, "pass %s timed out" % tag
             if r.returncode != 0:

@@ -113,6 +113,16 @@ HXR_DEV d3 ld3(const HXR_GLOBAL double* p) { return d3{p[0], p[1], p[2]}; }
 // whatever stands between it and the kernel's entry (an inline asm, a store the compiler cannot tell apart)
 #define HXR_CONSTANT __attribute__((address_space(4)))
 HXR_DEV d3 ld3(const HXR_CONSTANT double* p) { return d3{p[0], p[1], p[2]}; }
+template <class T>
+HXR_DEV T ld_const(const HXR_CONSTANT T* p)   // a whole record (a multiple of 4 bytes) from the constant address space
+{
+	T r;
+	const HXR_CONSTANT uint32_t* w = (const HXR_CONSTANT uint32_t*)p;
+	uint32_t* o = (uint32_t*)&r;
+#pragma unroll
+	for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = w[i];
+	return r;
+}
 HXR_DEV d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 HXR_DEV d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 HXR_DEV d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
@@ -809,7 +819,14 @@ HXR_DEV unsigned long long leaf_query(const HxrSceneDev& S, const HxrMeshDev& M,
 					if (i + 1 < count) asm volatile("s_load_dword %0, %2, 0x60\n\ts_load_dword %1, %2, 0xa0" : "=&s"(touch0), "=&s"(touch1) : "s"(T + i));
 					hits |= (int)triangle_decide(true, Dcr, ga, gb, gc, base + i, box, o, d, g);
 				} else {
+#ifdef HXR_CONST_TABLES
+					double Dcr, ga, gb, gc;
+					const HXR_CONSTANT HxrTriHot* Tc = (const HXR_CONSTANT HxrTriHot*)(T + i);
+					tri_products(ld3(Tc->N), ld3(Tc->A), ld3(Tc->AB), ld3(Tc->AC), o, nd, Dcr, ga, gb, gc);
+					hits |= (int)triangle_decide(true, Dcr, ga, gb, gc, base + i, box, o, d, g);
+#else
 					hits |= (int)triangle_test<false>(S, M, T[i], base + i, box, o, d, nd, g);
+#endif
 				}
 #endif
 			}
@@ -888,8 +905,13 @@ template <bool COUNT, bool TOUCH, int REPL>
 HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, GeomHit& g, const Stacks& st, Tally<COUNT>& tl)
 {
 	tl.template lap<PH_QUERY>();
+#ifdef HXR_CONST_TABLES
+	const HXR_CONSTANT HxrKdSlim* kd = (const HXR_CONSTANT HxrKdSlim*)(S.kd + M.kd_first);
+	const HXR_CONSTANT HxrKdBox* kd_box = (const HXR_CONSTANT HxrKdBox*)(S.kd_box + M.kd_first);
+#else
 	const HxrKdSlim* kd = S.kd + M.kd_first;
 	const HxrKdBox* kd_box = S.kd_box + M.kd_first;
+#endif
 	Box cb{ld3(M.bbox_min), ld3(M.bbox_max)};   // box of the current node (scalar registers); the root's is the mesh's
 	d3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
 	d3 nd = -d;
@@ -909,7 +931,11 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 	int sp = 0;
 	unsigned long long mask = alive;   // lanes taking part in the visit of the current node
 	if (in_root) tl.add(HC_KD);
+#ifdef HXR_CONST_TABLES
+	HxrKdSlim R = ld_const(kd);
+#else
 	HxrKdSlim R = kd[0];               // record of the current node (scalar registers)
+#endif
 	HXR_CHAIN_ARRIVE2(R.first, R.axis_count);
 	HXR_CHAIN_LAP(tl, PH4_KD_WAIT);
 	for (;;) {
@@ -926,7 +952,11 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 		} else {
 			const double split = R.split;
 			const int left = R.first;
+#ifdef HXR_CONST_TABLES
+			const HxrKdPair kids = ld_const((const HXR_CONSTANT HxrKdPair*)(kd + left));
+#else
 			const HxrKdPair kids = *(const HxrKdPair*)(kd + left);   // in flight while the children's boxes are being tested
+#endif
 			bool pl, pr;
 			kd_children_hit(cb, axis, split, o, inv, origin_in_root, mask, pl, pr);
 			if constexpr (COUNT) {   // instrumented builds: the children's slab answers against BBox::testIntersect taken literally, for the lanes of the visit (hxr_counters::box_test_mismatch)
@@ -996,8 +1026,13 @@ HXR_DEV bool mesh_query(const HxrSceneDev& S, const HxrMeshDev& M, d3 o, d3 d, G
 			if (S.dev_stats && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 63)) == (int)(threadIdx.x & 63)) { atomicAdd(S.dev_stats + 1, 1ull); if (!m) atomicAdd(S.dev_stats + 2, 1ull); }
 #endif
 			if (!m) continue;
+#ifdef HXR_CONST_TABLES
+			R = ld_const(kd + cn);
+			const HxrKdBox CB = ld_const(kd_box + cn);
+#else
 			R = kd[cn];
 			const HxrKdBox CB = kd_box[cn];
+#endif
 			HXR_CHAIN_LAP(tl, PH4_POP);
 			HXR_CHAIN_ARRIVE2(R.first, CB.hi[2]);
 			HXR_CHAIN_LAP(tl, PH4_KD_WAIT);

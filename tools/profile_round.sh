@@ -4,7 +4,7 @@
 tag=${1:-r03}
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sah-side --no-other-timings > $out/bench_under_rocprof.json 2> $out/bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sah-side --no-other-timings --no-live-pmc > $out/bench_under_rocprof.json 2> $out/bench.err
 cd $root
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/trace
