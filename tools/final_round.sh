@@ -26,5 +26,5 @@ find $out/aa_trace -name "*kernel_trace.csv" -exec cp {} $out/aa_kernel_trace.cs
 python3 tools/aa_timeline.py $out/aa_kernel_trace.csv > $out/aa_timeline.txt 2>&1
 bash tools/r4_ab2.sh $tag "-|A=1" "-|HXR_NO_PARTS_KERNEL=1" "-|HXR_NO_PARTS_KERNEL=1 HXR_NO_FRONT_PRIORITY=1 HXR_NO_FIRST_PRIORITY=1" > /dev/null 2>&1
 # the sharded pipeline end to end with four ranks on the one GPU (gloo gather; NOT a measurement): the assembled frame must equal the single-GPU frame
-HXR_BENCH_REHEARSAL=1 HXR_BENCH_VERIFY=1 timeout -k 10 400 python3 bench.py --gpus 4 --steps 3 --warmup 1 > $out/bench_rehearsal_4_ranks_one_gpu.json 2> $out/bench_rehearsal.err
+HXR_BENCH_REHEARSAL=1 HXR_BENCH_VERIFY=1 timeout -k 10 400 python3 bench.py --gpus 4 --steps 3 --warmup 1 2> $out/bench_rehearsal.err | grep "^{" > $out/bench_rehearsal_4_ranks_one_gpu.json
 tail -2 $out/bench.json | cut -c1-600; tail -8 $out/interactive_simple.txt; cat $out/ab.txt; tail -c 400 $out/bench_rehearsal_4_ranks_one_gpu.json; grep -i identical $out/bench_rehearsal.err
