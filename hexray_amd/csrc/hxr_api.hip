@@ -2034,6 +2034,18 @@ double hxr_last_kernel_ms(const hxr_scene* s)
 	return ms;
 }
 
+#ifdef HXR_WAVE_TIMELINE
+// developer aid (tools/wave_timeline.py): the four words per wave the render kernel of a -DHXR_WAVE_TIMELINE build leaves 8 MB into the side buffer
+int hxr_debug_wave_timeline(hxr_scene* s, unsigned long long* dst, size_t waves)
+{
+	if (!s->d_sched_side) return HXR_E_INVALID;
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(dst, (char*)s->d_sched_side + (8u << 20), waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemset((char*)s->d_sched_side + (8u << 20), 0, waves * 4 * sizeof(unsigned long long)));
+	return 0;
+}
+#endif
+
 int hxr_get_frame_timing(const hxr_scene* s, hxr_frame_timing* out)
 {
 	if (!s || !out) { set_err("null argument"); return HXR_E_INVALID; }

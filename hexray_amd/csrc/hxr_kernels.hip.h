@@ -2132,6 +2132,10 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	const uint32_t listed2 = P.sched2_items ? *P.sched2_count : 0u;   // the second list (HxrLaunch::sched2_items)
 	bool listed2_left = listed2 > 0;
 	bool listed2_now = listed2 > P.sched2_early_above;               // ... before the ordinary packets, or after them
+#ifdef HXR_WAVE_TIMELINE   // developer aid (tools/wave_timeline.py): when each wave started and left, and its longest packet, on the constant 100 MHz clock
+	const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+	unsigned long long wt_longest = 0, wt_longest_at = 0, wt_packets = 0;
+#endif
 	for (;;) {
 		if (P.cancel) {   // the host raised the cancel word (hxr_render): no further packets; every wave leaves through the common exit below.
 			// The word lives in pinned HOST memory mapped into the device (a copy engine or blit kernel could starve behind the persistent
@@ -2181,6 +2185,9 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		}
 		tl.template lap<PH_DISPENSE>();
 		const unsigned long long packet_t0 = __builtin_readcyclecounter();
+#ifdef HXR_WAVE_TIMELINE
+		const unsigned long long wt_packet_began = __builtin_amdgcn_s_memrealtime();
+#endif
 		const bool listed = single_pixel != 0xffffffffu;
 		if (P.front_priority) {   // (wave-uniform) see HxrLaunch::front_priority
 			if (from_front || (P.front_priority > 1 && listed)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
@@ -2403,6 +2410,13 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 			atomicMax(P.sched_cost + chunk, (uint32_t)(dt > 0xffffffffull ? 0xffffffffull : dt));
 		}
 		tl.template lap<PH_REDUCE>();
+#ifdef HXR_WAVE_TIMELINE
+		{
+			const unsigned long long now = __builtin_amdgcn_s_memrealtime(), began = wt_packet_began;
+			wt_packets++;
+			if (now - began > wt_longest) { wt_longest = now - began; wt_longest_at = began; }
+		}
+#endif
 #if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
 		{   // distribution of packet durations instead of the phase sums: slots = {sum, max, count, three thresholds}
 			const unsigned long long dt = __builtin_readcyclecounter() - packet_t0;
@@ -2420,6 +2434,12 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		}
 #endif
 	}
+#ifdef HXR_WAVE_TIMELINE
+	if (P.sched_side && lane == 0) {   // (the far end of the side buffer of the sample parts: 8 MB in, four words per wave)
+		unsigned long long* w = (unsigned long long*)((char*)P.sched_side + (8u << 20)) + 4 * ((size_t)blockIdx.x * (HXR_BLOCK / 64) + wave);
+		w[0] = wt_start; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = wt_longest; w[3] = wt_longest_at | (wt_packets << 48);
+	}
+#endif
 #ifdef HXR_PHASE_TIMERS
 	if (P.counters && lane == 0) {
 #ifdef HXR_PACKET_CLOCKS

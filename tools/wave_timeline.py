@@ -1,0 +1,50 @@
+"""Developer aid (a -DHXR_WAVE_TIMELINE build, tools/build_alt.sh wt -DHXR_WAVE_TIMELINE; HXR_HIP_LIB=hexray_amd/lib/libhexray_hip_wt.so): when the waves of
+the headline frame's render kernel start and leave, and their longest packets -- steady state against the first frame of a fresh handle.
+usage: HXR_HIP_LIB=... python3 tools/wave_timeline.py"""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import hexray_amd as hx
+hx.init(0)
+hs = hx.HostScene(os.path.join(ROOT, "data", "meshes.hexray"), hx.overlay_text(width=1920, height=1080, dof=True, num_samples=16))
+st = torch.cuda.current_stream().cuda_stream
+frame = torch.zeros((1080, 1920, 3), dtype=torch.float32, device="cuda")
+p = hx.frame_params(tile_size=64)
+lib = hx.hip_lib()
+lib.hxr_debug_wave_timeline.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+WAVES = 256 * 4 * 4
+def timeline(ds, label):
+    w = np.zeros((WAVES, 4), dtype=np.uint64)
+    rc = lib.hxr_debug_wave_timeline(ds._s, w.ctypes.data, WAVES)
+    assert rc == 0
+    w = w[w[:, 1] > 0]
+    t0 = w[:, 0].min()
+    start = (w[:, 0] - t0).astype(np.float64) / 100.0   # us
+    end = (w[:, 1] - t0).astype(np.float64) / 100.0
+    longest = w[:, 2].astype(np.float64) / 100.0
+    longest_at = ((w[:, 3] & np.uint64((1 << 48) - 1)) - t0).astype(np.float64) / 100.0
+    packets = (w[:, 3] >> np.uint64(48)).astype(np.int64)
+    q = lambda a, f: np.percentile(a, f)
+    print("%s: kernel %.3f ms; %d waves; starts by %.0f us (p99); a wave leaves at p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f us; packets per wave p50 %d (min %d, max %d)" % (
+        label, ds.last_kernel_ms(), len(w), q(start, 99), q(end, 10), q(end, 50), q(end, 90), q(end, 99), end.max(), q(packets, 50), packets.min(), packets.max()))
+    order = np.argsort(-longest)[:12]
+    print("   longest packets (us, began at us): " + "  ".join("%.0f@%.0f" % (longest[i], longest_at[i]) for i in order))
+    late = np.argsort(-end)[:8]
+    print("   last waves to leave (left at, their longest packet@began): " + "  ".join("%.0f:%.0f@%.0f" % (end[i], longest[i], longest_at[i]) for i in late), flush=True)
+def fresh(env, label, n=2):
+    for k, v in env.items(): os.environ[k] = v
+    for _ in range(n):
+        ds = hx.DeviceScene(hs)
+        ds.render_device(p, frame.data_ptr(), 1920 * 12, st); torch.cuda.synchronize()
+        timeline(ds, "first frame, " + label)
+        ds.close()
+    for k in env: del os.environ[k]
+ds = hx.DeviceScene(hs)
+for i in range(6):
+    ds.render_device(p, frame.data_ptr(), 1920 * 12, st); torch.cuda.synchronize()
+    if i >= 4: timeline(ds, "steady state")
+ds.close()
+fresh({}, "default (rectangle chunks listed, at the raised priority)")
+fresh({"HXR_NO_FIRST_PRIORITY": "1"}, "listed, no priority")
+fresh({"HXR_SCHED_NO_RECTS": "1"}, "nothing listed")
