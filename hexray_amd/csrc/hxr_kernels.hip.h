@@ -1950,6 +1950,9 @@ HXR_DEV f3 trace_sample(const HxrSceneDev& S, int W, int H, double x, double y, 
 	if ((F & HXR_F_EXTRA) == 0 || S.camera.stereo_separation == 0.0) {
 		camera_ray<(F & HXR_F_GI) != 0>(S, W, H, x, y, lu, lv, 0, o, d);
 		tl.template lap<PH_GEN>();
+#ifdef HXR_EXP_NO_TRACE   // developer aid: what a frame costs without the integrator (sample generation, dispenser, sample sums, stores)
+		return mkf((float)d.x, (float)d.y, (float)(o.x + o.y));
+#endif
 		f3 c = trace_rays<COUNT, F>(S, RayItem{o, d, mkf(1, 1, 1), 0, 0u, 0u}, rc, st, tl, dq);
 		tl.template lap<PH_SHADE>();
 		return c;
