@@ -526,10 +526,14 @@ Variant pick_variant(const hxr_scene* s)
 // The in-place Monte-Carlo mesh kernel exists at 4 and at 3 waves per SIMD (hxr_variants.h): four when every resident wave has a long queue of
 // packets (throughput), three when the launch is a few packets deep (one packet's latency): 2-way shards of the headline frame gain 6 % from the
 // fourth wave, 4-way shards nothing, 8-way shards lose 12 %.
+#define HXR_DEEP_LAUNCH 96u   // packets per resident wave from which a Monte-Carlo mesh launch counts as throughput-bound
 int mesh_mc_waves(const hxr_scene* s, uint32_t num_chunks)
 {
 	if (const char* e = getenv("HXR_MESH_MC_FOUR")) return atoi(e) ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES;   // developer aid
-	return num_chunks >= (uint32_t)s->num_cu * 4u * HXR_MESH_MC_WAVES * 24u ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES;
+	// Round 4: with its touch prefetch, priorities and replicating blocks the latency instance wins wherever a frame is shared -- per rank of the headline frame
+	// (steady state, ms, four waves against three): 2-way 3.69 / 3.55, 3-way 2.85 / 2.45, 4-way 2.39 / 1.96, 6-way 1.75 / 1.43, 8-way 1.62 / 1.13 -- and only the whole frame
+	// (126 packets per resident wave) keeps the fourth wave: 6.62 against 6.72.  The limit was 24 packets per resident wave, set before those measures existed.
+	return num_chunks >= (uint32_t)s->num_cu * 4u * HXR_MESH_MC_WAVES * HXR_DEEP_LAUNCH ? HXR_MESH_MC_WAVES : HXR_MESH_WAVES;
 }
 
 int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place, uint32_t num_chunks)
@@ -810,6 +814,9 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		const int sum_grid = (int)std::min<uint32_t>((n + 255u) / 256u, 64u);   // one 64-bit atomic per wave on ONE word: 4096 of them cost 50 us, 256 cost 3
 		// thresholds in multiples of the mean chunk cost: split into one-pixel packets / start first as a whole
 		uint32_t split_x = 16, first_x = 6;   // first_x re-measured in round 3 at four waves per SIMD: 6.74 ms at 1, 6.69 at 2, 6.56 at 3, 6.51 at 4 and 6, 6.56 at 8, 6.73 at 16
+		// ... and in round 4 for launches less than HXR_DEEP_LAUNCH packets deep per resident wave, where the tail is the late start of a packet of a few times the mean: 4
+		// (slowest 8-way rank of the headline frame 1.21 ms at 6, 1.17 at 5, 1.13 at 4, 1.15 at 3, 1.21 at 2; 2-way 3.86 / 3.62 at 6 / 4; the whole frame 6.62 / 6.66)
+		if (L.mode == 1 && n < (uint32_t)s->num_cu * 4u * 4u * HXR_DEEP_LAUNCH) first_x = 4;
 		if (const char* e = getenv("HXR_SCHED_SPLIT_X")) split_x = (uint32_t)atoi(e);   // developer aids
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
 		uint32_t frame_div = 1;   // "long against the frame": more than 1/frame_div of a wave's even share of the work (1 beat 2 and 4 at every N)
@@ -883,7 +890,9 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	L.sched_part_pixels = s->d_sched_part + HXR_PART_SLOTS;
 	L.sched_part_groups = (int32_t)part_groups;
 	// a launch a few packets deep per resident wave waits for its longest chain: the listed (long) packets get issue priority (HxrLaunch::front_priority)
-	L.front_priority = (n < (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, true, n) * 24u && !getenv("HXR_NO_FRONT_PRIORITY")) || getenv("HXR_FRONT_PRIORITY") ? 1 : 0;
+	// ... and so do all launches of the Monte-Carlo mesh kernel's latency instance (2- to 8-way shards of the headline frame: -0.5 ... -3 % with the lower `first_x`)
+	const bool latency_instance = pick_variant(s) == V_MESH && L.mode == 1 && mesh_mc_waves(s, n) == HXR_MESH_WAVES && HXR_MESH_WAVES != HXR_MESH_MC_WAVES;
+	L.front_priority = ((n < (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, true, n) * 24u || latency_instance) && !getenv("HXR_NO_FRONT_PRIORITY")) || getenv("HXR_FRONT_PRIORITY") ? 1 : 0;
 	// A frame without history: the chunks inside the screen rectangles -- where the long chains are, unsplit for want of measured costs -- run at the raised
 	// priority as well; once the list is through, the stragglers among them keep it against the ordinary packets (first frame of the headline 7.7 -> 7.15 ms)
 	if (!usable && !getenv("HXR_NO_FIRST_PRIORITY")) L.front_priority = 2;

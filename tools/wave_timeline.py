@@ -40,6 +40,16 @@ def fresh(env, label, n=2):
         timeline(ds, "first frame, " + label)
         ds.close()
     for k in env: del os.environ[k]
+if os.environ.get("HXR_SHARD"):   # "rank,count[,tile]": the steady state of one shard of the frame only, e.g. HXR_SHARD=0,8
+    v = [int(x) for x in os.environ["HXR_SHARD"].split(",")]
+    ps = hx.frame_params(tile_size=v[2] if len(v) > 2 else 8, shard_rank=v[0], shard_count=v[1], layout=hx.LAYOUT_TILES)
+    ds = hx.DeviceScene(hs, accel=hx.ACCEL_SAH if os.environ.get("HXR_ACCEL") == "sah" else hx.ACCEL_REFERENCE)
+    buf = torch.zeros(ds.output_bytes(ps, 0) // 4 + 16, dtype=torch.float32, device="cuda")
+    for i in range(7):
+        ds.render_device(ps, buf.data_ptr(), 0, st); torch.cuda.synchronize()
+        if i >= 4: timeline(ds, "shard %s, steady state" % os.environ["HXR_SHARD"])
+    ds.close()
+    sys.exit(0)
 ds = hx.DeviceScene(hs)
 for i in range(6):
     ds.render_device(p, frame.data_ptr(), 1920 * 12, st); torch.cuda.synchronize()
