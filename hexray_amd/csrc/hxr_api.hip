@@ -524,8 +524,7 @@ Variant pick_variant(const hxr_scene* s)
 // share of the frame" (hxr_sched_build_kernel).  A wrong figure here makes the split threshold swing from frame to frame: the 4-waves build of
 // the headline kernel ran 6.76 ... 7.77 ms with the 12 that used to be written here, and 6.84 with its own 16.
 // The in-place Monte-Carlo mesh kernel exists at 4 and at 3 waves per SIMD (hxr_variants.h): four when every resident wave has a long queue of
-// packets (throughput), three when the launch is a few packets deep (one packet's latency): 2-way shards of the headline frame gain 6 % from the
-// fourth wave, 4-way shards nothing, 8-way shards lose 12 %.
+// packets (throughput: the whole frame), three when the frame is shared or small (one packet's latency).
 #define HXR_DEEP_LAUNCH 96u   // packets per resident wave from which a Monte-Carlo mesh launch counts as throughput-bound
 int mesh_mc_waves(const hxr_scene* s, uint32_t num_chunks)
 {

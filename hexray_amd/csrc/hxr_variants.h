@@ -27,9 +27,9 @@
 // ... whose Monte-Carlo instances (render mode known at compile time) live in hxr_kernels_mesh_mc.hip, the one without refraction -- the headline
 // kernel -- compiled for FOUR waves per SIMD: 6.86 ms against 7.12 at three (the SAH frame 5.79 against 6.00) once the schedule is told the right number of
 // resident waves (resident_waves_per_cu, hxr_api.hip).  The instances whose mode arrives at launch (adaptive anti-aliasing, prepass, interactive)
-// lose 10 % at four waves and stay at HXR_MESH_WAVES.  So does a launch with little work per resident wave -- a shard of an 8-GPU frame, a 1-spp frame:
-// there one packet's chain of dependent steps is what the frame waits for, and a fourth wave on the SIMD only stretches it (slowest 8-way rank
-// 1.62 ms at four waves, 1.44 at three): mesh_mc_waves() in hxr_api.hip picks the instance per launch.  Round 4: the three-waves instance -- the latency
+// lose 10 % at four waves and stay at HXR_MESH_WAVES.  So does a launch with less than a whole frame's work per resident wave -- a rank's share of a
+// multi-GPU frame: there one packet's chain of dependent steps is what the frame waits for, and a fourth wave on the SIMD only stretches it (slowest 8-way rank
+// 1.62 ms at four waves, 1.13 at three; 2-way 3.69 / 3.55): mesh_mc_waves() in hxr_api.hip picks the instance per launch.  Round 4: the three-waves instance -- the latency
 // instance -- also prefetches the next hot record in its leaf loop (HXR_F_TOUCH: slowest 8-way rank 1.51 -> 1.36 ms; the throughput instance loses 6 % by it).
 #ifndef HXR_MESH_MC_WAVES
 #define HXR_MESH_MC_WAVES 4
