@@ -816,6 +816,9 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		// ... and in round 4 for launches less than HXR_DEEP_LAUNCH packets deep per resident wave, where the tail is the late start of a packet of a few times the mean: 4
 		// (slowest 8-way rank of the headline frame 1.21 ms at 6, 1.17 at 5, 1.13 at 4, 1.15 at 3, 1.21 at 2; 2-way 3.86 / 3.62 at 6 / 4; the whole frame 6.62 / 6.66)
 		if (L.mode == 1 && n < (uint32_t)s->num_cu * 4u * 4u * HXR_DEEP_LAUNCH) first_x = 4;
+		// ... and 2 for 1-spp passes (64 pixels per packet, ten packets per resident wave: every packet above the mean that starts late shows): simple 1 spp 0.72 ms at 6,
+		// 0.65 at 3, 0.62 at 2 and 1; meshes 1 spp 1.00 / 0.97 / 0.90 / 0.95; the adaptive-AA frame (its pass 1) 1.82 / 1.76 / 1.79 / 1.72
+		if (L.mode == 0) first_x = 2;
 		if (const char* e = getenv("HXR_SCHED_SPLIT_X")) split_x = (uint32_t)atoi(e);   // developer aids
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
 		uint32_t frame_div = 1;   // "long against the frame": more than 1/frame_div of a wave's even share of the work (1 beat 2 and 4 at every N)
