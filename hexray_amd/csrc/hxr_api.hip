@@ -1059,7 +1059,8 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
 			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
 		}
-		uint32_t heavy_x = 4;    // round 1, frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list); round 4, with the heavy pixels replicated: 4 / 8 / 16 / 32: 1.75 / 1.82 / 1.83 / 1.82
+		uint32_t heavy_x = 2;    // round 1, frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list); round 4, with the heavy pixels replicated: 4 / 8 / 16 / 32: 1.75 / 1.82 / 1.83 / 1.82;
+		                         // end of round 4 (medians of 40 frames, twice): 1 / 2 / 3 / 4: 1.83 / 1.74 / 1.78 / 1.80
 		if (const char* e = getenv("HXR_AA_HEAVY_X")) heavy_x = (uint32_t)atoi(e);   // developer aid
 		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * 8u);
 		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512),
