@@ -9,6 +9,6 @@ for w in heightfield16 cornell16 smallpt16; do
 	mkdir -p gpurun_out/${tag}_$w && rm -rf gpurun_out/${tag}_$w/pmc && cp -r $src/pmc_$w gpurun_out/${tag}_$w/pmc && python3 tools/profile_collect.py ${tag}_$w $w > /dev/null
 done
 # round 4 additions (when present): the lone chain's split, the adaptive-AA timeline, the A/B lines of the latency measures
-for f in chain_reference.txt chain_sah.txt aa_timeline.txt ab.txt bench_rehearsal_4_ranks_one_gpu.json; do [ -f $src/$f ] && cp $src/$f profiles/${tag}_$f; done
+for f in chain_reference.txt chain_sah.txt aa_timeline.txt ab.txt bench_rehearsal_4_ranks_one_gpu.json wave_timeline.txt shard_period.txt; do [ -f $src/$f ] && cp $src/$f profiles/${tag}_$f; done
 [ -f $src/ab.txt ] && mv profiles/${tag}_ab.txt profiles/${tag}_latency_measures_ab.txt
 true

@@ -25,6 +25,13 @@ timeout -k 10 120 hexray_amd/bin/hexray data/meshes.hexray --width 1920 --height
 find $out/aa_trace -name "*kernel_trace.csv" -exec cp {} $out/aa_kernel_trace.csv \; ; rm -rf $out/aa_trace
 python3 tools/aa_timeline.py $out/aa_kernel_trace.csv > $out/aa_timeline.txt 2>&1
 bash tools/r4_ab2.sh $tag "-|A=1" "-|HXR_NO_PARTS_KERNEL=1" "-|HXR_NO_PARTS_KERNEL=1 HXR_NO_FRONT_PRIORITY=1 HXR_NO_FIRST_PRIORITY=1" > /dev/null 2>&1
+# when every wave of the headline frame starts and leaves, steady state against the first frame of a fresh handle, and for one rank of the 8-way frame
+# (needs tools/build_alt.sh wt -DHXR_WAVE_TIMELINE beforehand)
+if [ -f hexray_amd/lib/libhexray_hip_wt.so ]; then
+	HXR_HIP_LIB=$PWD/hexray_amd/lib/libhexray_hip_wt.so timeout -k 10 200 python3 tools/wave_timeline.py 2>&1 | grep -v "Warn\|setattr\|return self\|amdgpu.ids" > $out/wave_timeline.txt
+	HXR_SHARD=0,8 HXR_HIP_LIB=$PWD/hexray_amd/lib/libhexray_hip_wt.so timeout -k 10 200 python3 tools/wave_timeline.py 2>&1 | grep -v "Warn\|setattr\|return self\|amdgpu.ids" | tail -6 >> $out/wave_timeline.txt
+fi
+timeout -k 10 100 python3 tools/exp_shard_period.py 8 2>&1 | grep period > $out/shard_period.txt
 # the sharded pipeline end to end with four ranks on the one GPU (gloo gather; NOT a measurement): the assembled frame must equal the single-GPU frame
 HXR_BENCH_REHEARSAL=1 HXR_BENCH_VERIFY=1 timeout -k 10 400 python3 bench.py --gpus 4 --steps 3 --warmup 1 2> $out/bench_rehearsal.err | grep "^{" > $out/bench_rehearsal_4_ranks_one_gpu.json
 tail -2 $out/bench.json | cut -c1-600; tail -8 $out/interactive_simple.txt; cat $out/ab.txt; tail -c 400 $out/bench_rehearsal_4_ranks_one_gpu.json; grep -i identical $out/bench_rehearsal.err
