@@ -525,6 +525,9 @@ Variant pick_variant(const hxr_scene* s)
 // the headline kernel ran 6.76 ... 7.77 ms with the 12 that used to be written here, and 6.84 with its own 16.
 // The in-place Monte-Carlo mesh kernel exists at 4 and at 3 waves per SIMD (hxr_variants.h): four when every resident wave has a long queue of
 // packets (throughput: the whole frame), three when the frame is shared or small (one packet's latency).
+// the control block of a scene (hxr_scene::d_work): [0..1023] dispenser counters and the AA count, [1024..1055] the schedule's control words (d_sched_ctl),
+// then HXR_PART_SLOTS part-done counters and HXR_PART_SLOTS part pixels (d_sched_part); all but the pixels are cleared at the start of every frame
+#define HXR_CONTROL_CLEARED_BYTES ((1024 + 32 + (size_t)HXR_PART_SLOTS) * sizeof(uint32_t))
 #define HXR_DEEP_LAUNCH 96u   // packets per resident wave from which a Monte-Carlo mesh launch counts as throughput-bound
 int mesh_mc_waves(const hxr_scene* s, uint32_t num_chunks)
 {
@@ -789,19 +792,9 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	if (!rc) rc = ensure((void**)&s->d_sched_items, &s->sched_items_cap, (size_t)capacity * sizeof(uint32_t));
 	if (!rc) rc = ensure((void**)&s->d_sched_side, &s->sched_side_cap, (size_t)HXR_PART_SLOTS * 64 * 3 * sizeof(float));
 	if (rc) return rc;
-	if (!s->d_sched_part) HIP_TRY(hipMalloc((void**)&s->d_sched_part, (size_t)HXR_PART_SLOTS * 2 * sizeof(uint32_t)));
-	HIP_TRY(hipMemsetAsync(s->d_sched_part, 0, (size_t)HXR_PART_SLOTS * sizeof(uint32_t), st));
-	if (!s->d_sched_ctl) HIP_TRY(hipMalloc((void**)&s->d_sched_ctl, 64));
+	// (d_sched_part and d_sched_ctl lie in the scene's control block, cleared at the start of the frame: render_on_stream)
 	const hxr_scene::SchedKey key = {p.W, p.H, p.mode, p.spp, p.tile, p.rank, p.count, n};
-	if (getenv("HXR_SCHED_VERBOSE") && s->sched_history) {   // developer aid: what the LAST frame's schedule listed (synchronises)
-		unsigned long long ctl[8] = {0};
-		if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(ctl, s->d_sched_ctl, sizeof ctl, hipMemcpyDeviceToHost) == hipSuccess) {
-			const uint32_t* w = (const uint32_t*)ctl;
-			fprintf(stderr, "[hxr] last schedule: total cost %llu, listed pixels / parts %u, whole chunks first %u, part slots %u\n", ctl[0], w[2], w[3], w[4]);
-		}
-	}
 	const bool usable = s->sched_history && memcmp(&key, &s->sched_key, sizeof key) == 0;
-	HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
 	// sample parts and single pixels go to the replicated-packet kernel where the scene's variant has one (words [10] count, [11] = 0, [12] ticket)
 	const bool use_parts = parts_kernel_for(s, L);
 	if (use_parts) {
@@ -939,7 +932,14 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 #else
 	const bool want_counter_buffer = counters;
 #endif
-	HIP_TRY(hipMemsetAsync(s->d_work, 0, 1024 * sizeof(uint32_t), st));
+	if (getenv("HXR_SCHED_VERBOSE") && s->sched_history) {   // developer aid: what the LAST frame's schedule listed (synchronises)
+		unsigned long long ctl[8] = {0};
+		if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(ctl, s->d_sched_ctl, sizeof ctl, hipMemcpyDeviceToHost) == hipSuccess) {
+			const uint32_t* w = (const uint32_t*)ctl;
+			fprintf(stderr, "[hxr] last schedule: total cost %llu, listed pixels / parts %u, whole chunks first %u, part slots %u\n", ctl[0], w[2], w[3], w[4]);
+		}
+	}
+	HIP_TRY(hipMemsetAsync(s->d_work, 0, HXR_CONTROL_CLEARED_BYTES, st));   // dispenser counters, schedule control words, part-done counters
 	if (want_counter_buffer) HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(hxr_counters), st));
 	s->counters_valid = want_counter_buffer;
 	s->frame_counts = counters;
@@ -1041,8 +1041,6 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		rc = ensure((void**)&s->d_sched_cost, &s->sched_cost_cap, (size_t)L.num_chunks * sizeof(uint32_t));
 		if (!rc) rc = ensure((void**)&s->d_sched_flags, &s->sched_flags_cap, (size_t)L.num_chunks);
 		if (rc) return rc;
-		if (!s->d_sched_ctl) HIP_TRY(hipMalloc((void**)&s->d_sched_ctl, 64));
-		HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st));
 		HIP_TRY(hipMemsetAsync(s->d_sched_cost, 0, (size_t)L.num_chunks * sizeof(uint32_t), st));
 		HIP_TRY(hipMemsetAsync(s->d_sched_flags, 0, (size_t)L.num_chunks, st));
 		L.sched_cost = s->d_sched_cost;
@@ -1510,8 +1508,11 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	if (s->arena.upload(d->environment.side_bitmap, 6, &d_sides)) return fail();
 	V.env_sides = d_sides;
 	void* p = nullptr;
-	if (s->arena.alloc(1024 * sizeof(uint32_t), &p)) return fail();
+	// one block: the dispenser counters, the schedule's control words and its part-slot counters -- ONE clear per frame (three fills cost a 1 ms launch 1 % each)
+	if (s->arena.alloc(HXR_CONTROL_CLEARED_BYTES + (size_t)HXR_PART_SLOTS * sizeof(uint32_t), &p)) return fail();
 	s->d_work = (uint32_t*)p;
+	s->d_sched_ctl = (unsigned long long*)(s->d_work + 1024);
+	s->d_sched_part = s->d_work + 1024 + 32;
 	if (s->arena.alloc(sizeof(hxr_counters), &p)) return fail();
 	s->d_counters = (unsigned long long*)p;
 #if defined(HXR_LEAF_STATS) || defined(HXR_TURN_STATS) || defined(HXR_LEAF_HIST) || defined(HXR_WALK_STATS)
@@ -2117,13 +2118,11 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->d_sched_cost) (void)hipFree(s->d_sched_cost);
 	if (s->d_sched_flags) (void)hipFree(s->d_sched_flags);
 	if (s->d_sched_items) (void)hipFree(s->d_sched_items);
-	if (s->d_sched_ctl) (void)hipFree(s->d_sched_ctl);
 	if (s->d_sched_items_r) (void)hipFree(s->d_sched_items_r);
 	if (s->parts_stream) (void)hipStreamDestroy(s->parts_stream);
 	if (s->ev_parts_go) (void)hipEventDestroy(s->ev_parts_go);
 	if (s->ev_parts_done) (void)hipEventDestroy(s->ev_parts_done);
 	if (s->d_sched_side) (void)hipFree(s->d_sched_side);
-	if (s->d_sched_part) (void)hipFree(s->d_sched_part);
 	if (s->d_queue) (void)hipFree(s->d_queue);
 	if (s->d_qctl) (void)hipFree(s->d_qctl);
 	if (s->d_accum) (void)hipFree(s->d_accum);
