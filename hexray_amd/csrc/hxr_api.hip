@@ -21,6 +21,7 @@
 // compiled in hxr_kernels_mesh.hip / hxr_kernels_mesh2.hip / hxr_kernels_heightfield.hip with their own flags
 HXR_VARIANTS_MESH_DEFER(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_INPLACE(HXR_DECLARE_EXTERN_LAUNCH_MODE)
+HXR_VARIANTS_MESH_INPLACE_MC_THROUGHPUT(HXR_DECLARE_EXTERN_MONTE_CARLO)
 HXR_VARIANTS_MESH_INPLACE_MC(HXR_DECLARE_EXTERN_MONTE_CARLO)
 HXR_VARIANTS_MESH_PARTS(HXR_DECLARE_EXTERN)
 HXR_VARIANTS_MESH_STACK1(HXR_DECLARE_EXTERN)

@@ -10,5 +10,4 @@
 #include "hxr_kernels.hip.h"
 #include "hxr_variants.h"
 
-HXR_VARIANTS_MESH_INPLACE_MC(HXR_INSTANTIATE_MONTE_CARLO)
-HXR_VARIANTS_MESH_PARTS(HXR_INSTANTIATE_MONTE_CARLO)
+HXR_VARIANTS_MESH_INPLACE_MC_THROUGHPUT(HXR_INSTANTIATE_MONTE_CARLO)   // the headline kernel; the three-waves instances live in hxr_kernels_mesh_lat.hip

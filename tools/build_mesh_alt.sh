@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p build/alt_$tag
 unit=${MESH_UNIT:-mesh_mc}
-if [ $unit = mesh_mc ]; then flags=${MESH_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-memory-clause}; other=build/hxr_kernels_mesh.o; else flags=${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp}; other=build/hxr_kernels_mesh_mc.o; fi
+if [ $unit = mesh_mc ]; then flags=${MESH_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-memory-clause}; other=build/hxr_kernels_mesh.o; else flags=${MESH_FLAGS:--O2 -mllvm -amdgpu-sched-strategy=max-ilp}; other=build/hxr_kernels_mesh_mc.o build/hxr_kernels_mesh_lat.o; fi
 hipcc --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude -Ihexray_amd/csrc $flags "$@" -c -o build/alt_$tag/mesh.o hexray_amd/csrc/hxr_kernels_$unit.hip
 hipcc --offload-arch=gfx950 -shared -o hexray_amd/lib/libhexray_hip_$tag.so build/hxr_api.o build/hxr_kd_build.o build/alt_$tag/mesh.o $other build/hxr_kernels_mesh2.o build/hxr_kernels_mesh_gi.o build/hxr_kernels_heightfield.o build/hxr_kernels_nested.o
 python3 tools/kernel_resources.py build/alt_$tag/mesh.o | grep "<false, 1u, [0-9], 1>" | cut -c1-140
