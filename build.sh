@@ -27,11 +27,14 @@ if [ "$what" = all ] || [ "$what" = hip ]; then
 	# as per-lane 0/1 words glued together with shifts (meshes16 7.40 -> 7.18 ms without it, cornell16 52.1 -> 50.5, kdtree_test 10.0 -> 9.55)
 	HIPFLAGS="--offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude -Ihexray_amd/csrc $HXR_EXTRA_HIPFLAGS"
 	MESH_TU_FLAGS="-O2 -mllvm -amdgpu-sched-strategy=max-ilp"
-	MESH_LAT_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-memory-clause"   # the three-waves Monte-Carlo mesh instances (hxr_kernels_mesh_lat.hip)
+	# the three-waves Monte-Carlo mesh instances (hxr_kernels_mesh_lat.hip): slowest 8-way rank of the headline frame 1.13 ms with -O1 / max-memory-clause, 1.19 with the
+	# register-pressure trackers added, 1.13 with max-ilp alone, 1.105 with max-ilp AND the trackers (sum of the eight ranks 8.87 -> 8.65)
+	MESH_LAT_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers=1"
 	# the headline kernel (hxr_kernels_mesh_mc.hip): 6.57 ms with max-memory-clause, against 6.78 with max-ilp and 7.25 at -O2; end of round 4: LLVM's AMDGPU register-pressure
-	# trackers on top (57 spilled registers instead of 65, another schedule): 6.60 -> 6.42 ms, the SAH frame 5.64 -> 5.47.  The other units lose by that flag (cornell16 +3.5 %,
-	# heightfield16 +1 %, slowest 8-way rank +4 %) and the catch-all unit built with it fails the exec-prologue gate below
-	MESH_MC_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-memory-clause -mllvm -amdgpu-use-amdgpu-trackers=1"
+	# trackers on top (57 spilled registers instead of 65, another schedule): 6.60 -> 6.42 ms, the SAH frame 5.64 -> 5.47.  The GI and heightfield units lose by that flag (cornell16 +3.5 %,
+	# heightfield16 +1 %; with max-ilp as well: +0 %, +15 %), the sphere path tracer's unit gains 0.3 %, and the catch-all unit built with it fails the exec-prologue gate below
+	# ... and, with the trackers, the max-ilp strategy again: 6.53 -> 6.42 on the same box (max-memory-clause had beaten max-ilp without them); the iterative strategies 6.49 (maxocc), 6.71 (minreg)
+	MESH_MC_TU_FLAGS="-O1 -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers=1"
 	HF_TU_FLAGS="-O1"    # the heightfield marcher at 3 waves per SIMD: -O1 keeps its spills out of the marching loop (7.77 ms against 9.04 at -O2)
 	NESTED_TU_FLAGS="-O2"
 	# NOT max-memory-clause for the catch-all unit, although it measured faster (kdtree_test 9.73 -> 9.23 ms): with that strategy LLVM (ROCm 7.2) emits, in

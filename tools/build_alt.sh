@@ -17,9 +17,9 @@ hipcc $HIPFLAGS ${MESH_GI_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-memory-cl
 p6=$!
 hipcc $HIPFLAGS -O2 -c -o build/alt_$tag/nested.o hexray_amd/csrc/hxr_kernels_nested.hip &
 p4=$!
-hipcc $HIPFLAGS ${MESH_MC_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-memory-clause -mllvm -amdgpu-use-amdgpu-trackers=1} -c -o build/alt_$tag/mesh_mc.o hexray_amd/csrc/hxr_kernels_mesh_mc.hip &
+hipcc $HIPFLAGS ${MESH_MC_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers=1} -c -o build/alt_$tag/mesh_mc.o hexray_amd/csrc/hxr_kernels_mesh_mc.hip &
 p5=$!
-hipcc $HIPFLAGS ${MESH_LAT_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-memory-clause} -c -o build/alt_$tag/mesh_lat.o hexray_amd/csrc/hxr_kernels_mesh_lat.hip &
+hipcc $HIPFLAGS ${MESH_LAT_FLAGS:--O1 -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers=1} -c -o build/alt_$tag/mesh_lat.o hexray_amd/csrc/hxr_kernels_mesh_lat.hip &
 p7=$!
 hipcc $HIPFLAGS -O3 -c -o build/alt_$tag/kd.o hexray_amd/csrc/hxr_kd_build.hip
 hipcc $HIPFLAGS ${API_FLAGS:--O3 -mllvm -amdgpu-sched-strategy=max-memory-clause} -c -o build/alt_$tag/api.o hexray_amd/csrc/hxr_api.hip
