@@ -148,7 +148,7 @@ struct hxr_scene {
 	uint32_t* watch_tiles = nullptr;
 	int device = 0;
 	uint32_t* d_surface = nullptr;      size_t surface_bytes = 0;   // hxr_interactive_frame: the 32-bit display pixels before they leave
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;   // the frame's first and last event: ALIASES of ev_pass[..][0] / [..][3] (an event record is a barrier packet: ~5 us of the stream each)
 	hipEvent_t ev_pass[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per pass: before render, after render, after continuation, after resolve
 	int passes_timed = 0;
 	bool pass_deferred[2] = {false, false};
@@ -628,7 +628,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 	bool defer = false;
 	int rc = plan_defer(s, p, L, pass, st, defer);
 	if (rc) return rc;
-	if (timed & TIME_BEGIN) { HIP_TRY(hipEventRecord(s->ev0, st)); s->passes_timed = 0; }
+	if (timed & TIME_BEGIN) { s->ev0 = s->ev_pass[pass][0]; s->passes_timed = 0; }
 	s->pass_deferred[pass] = defer;
 	HIP_TRY(hipEventRecord(s->ev_pass[pass][0], st));
 	const HxrSceneDev& V = s->host_view;
@@ -713,7 +713,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		HIP_TRY(hipGetLastError());
 	}
 	if (parts_launched) HIP_TRY(hipStreamWaitEvent(st, s->ev_parts_done, 0));
-	HIP_TRY(hipEventRecord(s->ev_pass[pass][1], st));
+	if (defer) HIP_TRY(hipEventRecord(s->ev_pass[pass][1], st));   // (a pass without a continuation has two events only: before and after)
 	if (defer) {
 		// the number of queued rays stays on the device: a fixed grid of persistent waves drains the sub-queues
 		s->accum_dirty = true;
@@ -743,14 +743,12 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		hipLaunchKernelGGL(hxr_resolve_kernel, dim3(rgrid), dim3(HXR_BLOCK), 0, st, L, scale);
 		HIP_TRY(hipGetLastError());
 		s->accum_dirty = false;   // enqueued: the accumulator is zero again when this stream gets there
-	} else {
-		HIP_TRY(hipEventRecord(s->ev_pass[pass][2], st));
 	}
 	HIP_TRY(hipEventRecord(s->ev_pass[pass][3], st));
 	s->passes_timed = pass + 1;
 #undef HXR_KERNEL_ARGS
 #undef HXR_KERNEL_ARGS_OF
-	if (timed & TIME_END) { HIP_TRY(hipEventRecord(s->ev1, st)); s->timed = true; }
+	if (timed & TIME_END) { s->ev1 = s->ev_pass[pass][3]; s->timed = true; }
 	return 0;
 }
 
@@ -1538,7 +1536,6 @@ hxr_scene* hxr_scene_create_ex(const hxr_scene_desc* d, const hxr_scene_options*
 	const uint8_t* dl = nullptr;
 	if (s->arena.upload(lut, 4097, &dl)) return fail();
 	s->d_lut = const_cast<uint8_t*>(dl);
-	if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
 	for (int pass = 0; pass < 2; pass++)
 		for (int k = 0; k < 4; k++)
 			if (hipEventCreate(&s->ev_pass[pass][k]) != hipSuccess) { set_err("hipEventCreate failed"); return fail(); }
@@ -2071,9 +2068,11 @@ int hxr_get_frame_timing(const hxr_scene* s, hxr_frame_timing* out)
 	out->total_ms = ms;
 	for (int pass = 0; pass < s->passes_timed; pass++) {
 		float a = 0, b = 0, c = 0;
-		HIP_TRY(hipEventElapsedTime(&a, s->ev_pass[pass][0], s->ev_pass[pass][1]));
-		HIP_TRY(hipEventElapsedTime(&b, s->ev_pass[pass][1], s->ev_pass[pass][2]));
-		HIP_TRY(hipEventElapsedTime(&c, s->ev_pass[pass][2], s->ev_pass[pass][3]));
+		if (s->pass_deferred[pass]) {
+			HIP_TRY(hipEventElapsedTime(&a, s->ev_pass[pass][0], s->ev_pass[pass][1]));
+			HIP_TRY(hipEventElapsedTime(&b, s->ev_pass[pass][1], s->ev_pass[pass][2]));
+			HIP_TRY(hipEventElapsedTime(&c, s->ev_pass[pass][2], s->ev_pass[pass][3]));
+		} else HIP_TRY(hipEventElapsedTime(&a, s->ev_pass[pass][0], s->ev_pass[pass][3]));
 		out->render_ms += a;
 		out->continue_ms += b;
 		out->resolve_ms += c;
@@ -2134,8 +2133,6 @@ void hxr_scene_destroy(hxr_scene* s)
 	if (s->main_stream) (void)hipStreamDestroy(s->main_stream);
 	if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
 	if (s->ev_done) (void)hipEventDestroy(s->ev_done);
-	if (s->ev0) (void)hipEventDestroy(s->ev0);
-	if (s->ev1) (void)hipEventDestroy(s->ev1);
 	for (int pass = 0; pass < 2; pass++)
 		for (int k = 0; k < 4; k++)
 			if (s->ev_pass[pass][k]) (void)hipEventDestroy(s->ev_pass[pass][k]);
