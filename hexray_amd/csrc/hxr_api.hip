@@ -815,11 +815,15 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 		if (const char* e = getenv("HXR_SCHED_FIRST_X")) first_x = (uint32_t)atoi(e);
 		uint32_t frame_div = 1;   // "long against the frame": more than 1/frame_div of a wave's even share of the work (1 beat 2 and 4 at every N)
 		if (const char* e = getenv("HXR_SCHED_FRAME_DIV")) frame_div = (uint32_t)atoi(e);
-		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl);
+		// launches a few packets deep per resident wave list their costliest chunks first, in a phase of their own (hxr_sched_build_kernel; HXR_SCHED_ONE_PHASE=1: A/B aid)
+		const bool two_phases = !(L.mode == 1 && n >= (uint32_t)s->num_cu * 4u * 4u * HXR_DEEP_LAUNCH) && !getenv("HXR_SCHED_ONE_PHASE");
+		uint32_t* const largest = (uint32_t*)s->d_sched_ctl + 14;
+		hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sum_grid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, n, s->d_sched_ctl, two_phases ? largest : (uint32_t*)nullptr);
+		for (uint32_t phase = two_phases ? 1u : 0u; phase <= (two_phases ? 2u : 0u); phase++)
 		hipLaunchKernelGGL(hxr_sched_build_kernel, dim3(grid), dim3(256), 0, st, s->d_sched_cost, n, (uint32_t)L.pixels_per_chunk, num_pixels,
 		                   (const unsigned long long*)s->d_sched_ctl, split_x, first_x, (uint32_t)s->num_cu * (uint32_t)resident_waves_per_cu(s, L.mode, defer_capacity(s, L.num_chunks, L.spp) == 0 && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr), n), frame_div, part_groups, s->d_sched_flags, s->d_sched_items, capacity,
 		                   s->d_sched_part + HXR_PART_SLOTS, (uint32_t*)s->d_sched_ctl + 2, use_parts ? s->d_sched_items_r : (uint32_t*)nullptr, (uint32_t*)s->d_sched_ctl + 10,
-		                   lanes_per_pixel <= 16 ? 1u : 0u);
+		                   lanes_per_pixel <= 16 ? 1u : 0u, phase, (const uint32_t*)largest);
 		HIP_TRY(hipGetLastError());
 	} else {
 		// No cost map yet.  Where can long chains of secondary rays be?  Only on the screen footprint of nodes whose shaders spawn them:
@@ -1054,7 +1058,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		if (cost_aware) {
 			if (schedule_pass1) { HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st)); s->sched_frame = false; }   // pass 1's list counters are done with; the words now serve pass 3
 			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
-			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl);
+			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl, (uint32_t*)nullptr);
 		}
 		uint32_t heavy_x = 2;    // round 1, frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list); round 4, with the heavy pixels replicated: 4 / 8 / 16 / 32: 1.75 / 1.82 / 1.83 / 1.82;
 		                         // end of round 4 (medians of 40 frames, twice): 1 / 2 / 3 / 4: 1.83 / 1.74 / 1.78 / 1.80

@@ -2137,7 +2137,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	bool listed2_now = listed2 > P.sched2_early_above;               // ... before the ordinary packets, or after them
 #ifdef HXR_WAVE_TIMELINE   // developer aid (tools/wave_timeline.py): when each wave started and left, and its longest packet, on the constant 100 MHz clock
 	const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
-	unsigned long long wt_longest = 0, wt_longest_at = 0, wt_packets = 0;
+	unsigned long long wt_longest = 0, wt_longest_at = 0, wt_packets = 0, wt_longest_kind = 0;   // kind: 1 listed, 2 one pixel, 4 sample part, 8 from the front of the list
 #endif
 	for (;;) {
 		if (P.cancel) {   // the host raised the cancel word (hxr_render): no further packets; every wave leaves through the common exit below.
@@ -2417,7 +2417,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 		{
 			const unsigned long long now = __builtin_amdgcn_s_memrealtime(), began = wt_packet_began;
 			wt_packets++;
-			if (now - began > wt_longest) { wt_longest = now - began; wt_longest_at = began; }
+			if (now - began > wt_longest) { wt_longest = now - began; wt_longest_at = began; wt_longest_kind = (listed ? 1u : 0u) | (single ? 2u : 0u) | (part ? 4u : 0u) | (from_front ? 8u : 0u); }
 		}
 #endif
 #if defined(HXR_PHASE_TIMERS) && defined(HXR_PACKET_CLOCKS)
@@ -2440,7 +2440,7 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 #ifdef HXR_WAVE_TIMELINE
 	if (P.sched_side && lane == 0) {   // (the far end of the side buffer of the sample parts: 8 MB in, four words per wave)
 		unsigned long long* w = (unsigned long long*)((char*)P.sched_side + (8u << 20)) + 4 * ((size_t)blockIdx.x * (HXR_BLOCK / 64) + wave);
-		w[0] = wt_start; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = wt_longest; w[3] = wt_longest_at | (wt_packets << 48);
+		w[0] = wt_start; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = wt_longest; w[3] = (wt_longest_at & ((1ull << 48) - 1)) | ((wt_packets & 0xfffull) << 48) | (wt_longest_kind << 60);
 	}
 #endif
 #ifdef HXR_PHASE_TIMERS
@@ -2573,12 +2573,15 @@ __global__ __launch_bounds__(((F & HXR_F_LANEWALK) != 0 ? HXR_LANE_BLOCK : HXR_B
 
 #ifndef HXR_RENDER_KERNEL_ONLY   // the small kernels below live in hxr_api.hip only
 // Adaptive schedule, step 1: total cost of the previous frame's chunks.
-__global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t n, unsigned long long* total)
+// `largest` (may be null): receives the largest chunk cost as well (hxr_sched_build_kernel's two phases)
+__global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t n, unsigned long long* total, uint32_t* largest)
 {
 	unsigned long long s = 0;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += cost[i];
-	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	uint32_t m = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t c = cost[i]; s += c; m = max(m, c); }
+	for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); m = max(m, (uint32_t)__shfl_down((int)m, off, 64)); }
 	if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+	if ((threadIdx.x & 63) == 0 && largest && m) atomicMax(largest, m);
 }
 
 // Step 2: chunks that cost more than `split_x` times the mean are listed pixel by pixel from the front of `items` (their
@@ -2590,8 +2593,13 @@ __global__ void hxr_sched_sum_kernel(const uint32_t* __restrict__ cost, uint32_t
 // when `route_pixels` (a pixel's samples fit 16 lanes).  They then do not appear in `items`.
 __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc, uint32_t num_pixels, const unsigned long long* total, uint32_t split_x,
                                        uint32_t first_x, uint32_t resident_waves, uint32_t frame_div, uint32_t part_groups, uint8_t* flags, uint32_t* items, uint32_t capacity,
-                                       uint32_t* part_pixels, uint32_t* counts, uint32_t* items_r, uint32_t* count_r, uint32_t route_pixels)
+                                       uint32_t* part_pixels, uint32_t* counts, uint32_t* items_r, uint32_t* count_r, uint32_t route_pixels, uint32_t phase, const uint32_t* largest)
 {
+	// `phase` (round 4): the lists are filled in the order the atomics land, and in a launch a few packets deep per wave the front list is longer than one round
+	// of the resident waves -- the one-pixel packets of the costliest chunk of a 1-spp frame (0.7 ms chains in a 0.9 ms frame) began 0.2 ms late.  Such launches run this
+	// kernel twice: phase 1 lists the chunks that cost at least half of the costliest (their pixels / parts / themselves: the first entries of every list), phase 2 the
+	// rest.  phase 0: everything in one go (whole frames: the tail is elsewhere).  Only phases 0 and 2 clear `cost`.
+	const unsigned long long top_above = phase ? max(1ull, (unsigned long long)*largest / 2ull) : 0ull;
 	uint32_t* part_items = items_r ? items_r : items;
 	uint32_t* part_count = items_r ? count_r : counts + 0;
 	uint32_t* pixel_items = items_r && route_pixels ? items_r : items;
@@ -2602,7 +2610,9 @@ __global__ void hxr_sched_build_kernel(uint32_t* cost, uint32_t n, uint32_t ppc,
 	const unsigned long long split_above = max((unsigned long long)split_x * mean, *total / (resident_waves ? resident_waves : 1u) / (frame_div ? frame_div : 1u));
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const unsigned long long c = cost[i];
-		cost[i] = 0;
+		if (phase == 1 && c < top_above) continue;                      // its turn comes in phase 2
+		if (phase != 1) cost[i] = 0;
+		if (phase == 2 && c >= top_above) continue;                     // listed in phase 1
 		const uint32_t first = i * ppc;
 		const bool heavy = mean > 0 && c > (unsigned long long)first_x * mean && first < num_pixels;
 		if (heavy) {

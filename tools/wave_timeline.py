@@ -7,7 +7,13 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import hexray_amd as hx
 hx.init(0)
-hs = hx.HostScene(os.path.join(ROOT, "data", "meshes.hexray"), hx.overlay_text(width=1920, height=1080, dof=True, num_samples=16))
+if os.environ.get("HXR_WL"):   # another bench workload (steady state and first frame only), e.g. HXR_WL=meshes1
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    scene_name, ov, desc = bench.WORKLOADS[os.environ["HXR_WL"]]
+    hs = hx.HostScene(os.path.join(ROOT, "data", scene_name), hx.overlay_text(**ov))
+else:
+    hs = hx.HostScene(os.path.join(ROOT, "data", "meshes.hexray"), hx.overlay_text(width=1920, height=1080, dof=True, num_samples=16))
 st = torch.cuda.current_stream().cuda_stream
 frame = torch.zeros((1080, 1920, 3), dtype=torch.float32, device="cuda")
 p = hx.frame_params(tile_size=64)
@@ -24,12 +30,14 @@ def timeline(ds, label):
     end = (w[:, 1] - t0).astype(np.float64) / 100.0
     longest = w[:, 2].astype(np.float64) / 100.0
     longest_at = ((w[:, 3] & np.uint64((1 << 48) - 1)) - t0).astype(np.float64) / 100.0
-    packets = (w[:, 3] >> np.uint64(48)).astype(np.int64)
+    packets = ((w[:, 3] >> np.uint64(48)) & np.uint64(0xfff)).astype(np.int64)
+    kind = (w[:, 3] >> np.uint64(60)).astype(np.int64)   # of the wave's longest packet: 1 listed, 2 one pixel, 4 sample part, 8 from the front of the list
+    kinds = {0: "chunk", 1: "listed chunk", 9: "front chunk", 3: "pixel (back)", 11: "pixel", 5: "part (back)", 13: "part"}
     q = lambda a, f: np.percentile(a, f)
     print("%s: kernel %.3f ms; %d waves; starts by %.0f us (p99); a wave leaves at p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f us; packets per wave p50 %d (min %d, max %d)" % (
         label, ds.last_kernel_ms(), len(w), q(start, 99), q(end, 10), q(end, 50), q(end, 90), q(end, 99), end.max(), q(packets, 50), packets.min(), packets.max()))
     order = np.argsort(-longest)[:12]
-    print("   longest packets (us, began at us): " + "  ".join("%.0f@%.0f" % (longest[i], longest_at[i]) for i in order))
+    print("   longest packets (us, began at us): " + "  ".join("%.0f@%.0f %s" % (longest[i], longest_at[i], kinds.get(int(kind[i]), str(int(kind[i])))) for i in order))
     late = np.argsort(-end)[:8]
     print("   last waves to leave (left at, their longest packet@began): " + "  ".join("%.0f:%.0f@%.0f" % (end[i], longest[i], longest_at[i]) for i in late), flush=True)
 def fresh(env, label, n=2):
