@@ -123,6 +123,7 @@ struct hxr_scene {
 	bool frame_counts = false;          // the frame being rendered collects work counters (the counting kernels take every packet themselves)
 	bool sched_history = false;
 	bool sched_frame = false;           // the last frame went through prepare_schedule (hxr_frame_timing::sched_*)
+	bool sched_sum_valid = false;       // ... and d_sched_ctl[0] holds the cost total it was scheduled with (there was a usable cost map)
 	bool aa_cost_aware = false;         // the last frame was an adaptive-AA frame whose flagged list has a back part
 	uint8_t* d_lut = nullptr;
 	// deferred secondary rays (HXR_F_DEFER variants; plan_defer)
@@ -910,6 +911,7 @@ int prepare_schedule(hxr_scene* s, const Plan& p, HxrLaunch& L, uint32_t num_pix
 	s->sched_key = key;
 	s->sched_history = true;
 	s->sched_frame = true;
+	s->sched_sum_valid = usable;
 	return 0;
 }
 
@@ -950,6 +952,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	s->timed = false;
 	s->aa_cost_aware = false;
 	s->sched_frame = false;
+	s->sched_sum_valid = false;
 	HxrLaunch L;
 	fill_launch(s, p, L);
 	s->no_defer_this_frame = p.mode == HXR_MODE_PREPASS;
@@ -1056,9 +1059,13 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 	if (rc) return rc;
 	if (tile_pixels) {
 		if (cost_aware) {
-			if (schedule_pass1) { HIP_TRY(hipMemsetAsync(s->d_sched_ctl, 0, 64, st)); s->sched_frame = false; }   // pass 1's list counters are done with; the words now serve pass 3
-			const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
-			hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl, (uint32_t*)nullptr);
+			// Pass 3 has control words of its own ([24] [25] counts, [27] ticket: cleared with the block at the start of the frame), so nothing is cleared between the passes;
+			// and the mean chunk cost its "heavy" threshold needs is the one pass 1 was scheduled with -- the previous frame's, [0] -- when there was one: no second sum
+			// (a fill, a kernel and their launch gaps: 20 us of a 1.6 ms frame).  A first frame sums this frame's costs as before ([0] is still zero then).
+			if (!(schedule_pass1 && s->sched_sum_valid)) {
+				const int sgrid = (int)std::min<uint32_t>((L.num_chunks + 255u) / 256u, 64u);
+				hipLaunchKernelGGL(hxr_sched_sum_kernel, dim3(sgrid), dim3(256), 0, st, (const uint32_t*)s->d_sched_cost, L.num_chunks, s->d_sched_ctl, (uint32_t*)nullptr);
+			}
 		}
 		uint32_t heavy_x = 2;    // round 1, frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list); round 4, with the heavy pixels replicated: 4 / 8 / 16 / 32: 1.75 / 1.82 / 1.83 / 1.82;
 		                         // end of round 4 (medians of 40 frames, twice): 1 / 2 / 3 / 4: 1.83 / 1.74 / 1.78 / 1.80
@@ -1066,7 +1073,7 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * 8u);
 		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512),
 		                   cost_aware ? (const uint32_t*)s->d_sched_cost : (const uint32_t*)nullptr, (const unsigned long long*)s->d_sched_ctl, L.num_chunks,
-		                   cost_aware ? (uint32_t*)s->d_sched_ctl + 3 : (uint32_t*)nullptr, list_capacity, heavy_x);
+		                   cost_aware ? (uint32_t*)s->d_sched_ctl + 25 : (uint32_t*)nullptr, list_capacity, heavy_x);
 		HIP_TRY(hipGetLastError());
 	}
 	// pass 3: the flagged-pixel count stays on the device; launch enough waves for the worst case and let them drain
@@ -1089,8 +1096,8 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		L3.front_priority = getenv("HXR_NO_FRONT_PRIORITY") ? 0 : 2;   // ... and at the raised priority: they are this pass's long chains
 		L3.sched_items = (const uint32_t*)s->d_aa_list;
 		L3.sched_capacity = list_capacity;
-		L3.sched_counts = (const uint32_t*)s->d_sched_ctl + 2;   // [2] stays 0 (nothing from the front), [3] = pixels at the back
-		L3.sched_ticket = (uint32_t*)s->d_sched_ctl + 5;
+		L3.sched_counts = (const uint32_t*)s->d_sched_ctl + 24;   // [24] stays 0 (nothing from the front), [25] = pixels at the back
+		L3.sched_ticket = (uint32_t*)s->d_sched_ctl + 27;
 	}
 	L3.num_chunks = (tile_pixels + (uint32_t)L3.pixels_per_chunk - 1u) / (uint32_t)L3.pixels_per_chunk;
 	L3.work_counter = s->d_work + 256;
@@ -2035,7 +2042,7 @@ int hxr_get_counters(const hxr_scene* s, hxr_counters* out)
 	for (int i = 0; i < PH_NUM; i++) out->reserved_[i] = raw[HC_NUM + i];   // zero unless built with -DHXR_PHASE_TIMERS
 	uint32_t flagged = 0, flagged_heavy = 0;
 	HIP_TRY(hipMemcpy(&flagged, s->d_work + 512, sizeof flagged, hipMemcpyDeviceToHost));
-	if (s->aa_cost_aware) HIP_TRY(hipMemcpy(&flagged_heavy, (uint32_t*)s->d_sched_ctl + 3, sizeof flagged_heavy, hipMemcpyDeviceToHost));   // the back of the list
+	if (s->aa_cost_aware) HIP_TRY(hipMemcpy(&flagged_heavy, (uint32_t*)s->d_sched_ctl + 25, sizeof flagged_heavy, hipMemcpyDeviceToHost));   // the back of the list
 	out->aa_pixels = (uint64_t)flagged + flagged_heavy;
 	return 0;
 }
