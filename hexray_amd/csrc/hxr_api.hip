@@ -482,10 +482,14 @@ int parts_grid(const hxr_scene* s)   // blocks of the replicating instance launc
 	return std::max(1, s->num_cu * HXR_MESH_WAVES * 3 / 16);   // slowest 8-way rank: 1.84 ms at 48 blocks, 1.24-1.34 at 96, 1.22 at 144, 1.20-1.21 at 192 (sum of ranks 9.5 / 9.5 / 9.6)
 }
 
-int grid_for(const hxr_scene* s, uint32_t chunks)
+int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place, uint32_t num_chunks);
+int grid_for(const hxr_scene* s, uint32_t chunks, int blocks_per_cu)
 {
-	// persistent waves: enough blocks to fill every CU several times over, never more than the work
-	uint32_t blocks = (uint32_t)s->num_cu * 8u;
+	// persistent waves: exactly the blocks a CU holds at the variant's occupancy (`blocks_per_cu`; end of round 4), never more than the work.  It used to be eight
+	// per CU whatever the variant: the blocks beyond the resident ones start as the first ones leave, find the dispensers empty and leave -- at the very time the
+	// frame waits for its last packets (headline 6.35 -> 6.30 ms at four per CU, 6.37 at sixteen; heightfield16 7.81 -> 7.76 at three; one block too few costs 14 %)
+	uint32_t blocks = (uint32_t)s->num_cu * (uint32_t)std::max(1, blocks_per_cu);
+	if (const char* e = getenv("HXR_GRID_PER_CU")) blocks = (uint32_t)s->num_cu * (uint32_t)std::max(1, atoi(e));   // developer aid
 	uint32_t need = (chunks + (HXR_BLOCK / 64) - 1) / (HXR_BLOCK / 64);
 	return (int)std::max(1u, std::min(blocks, need));
 }
@@ -653,7 +657,9 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 	}
 	s->parts_pending = false;
 	if (L.num_chunks > 0) {
-		int grid = grid_for(s, L.num_chunks);
+		// (instrumented launches run variants of other occupancies than the table knows: eight per CU as before)
+		// ... and so do launches a few packets deep per wave (1-spp passes: 0.593 ms with eight, 0.600 with the exact count)
+		int grid = grid_for(s, L.num_chunks, counters || L.num_chunks < (uint32_t)s->num_cu * 16u * 24u ? 8 : resident_waves_per_cu(s, L.mode, !defer && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr), L.num_chunks) / (HXR_BLOCK / 64));
 		// beside the replicating blocks the main kernel is launched with exactly the blocks that fit the machine with them (three blocks of four waves per CU at
 		// three waves per SIMD): whichever kernel the dispatcher starts first, the other finds its room
 		if (parts_launched) grid = std::max(1, std::min(grid, s->num_cu * HXR_MESH_WAVES - parts_grid(s)));
