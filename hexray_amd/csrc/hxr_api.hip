@@ -479,7 +479,7 @@ void fill_launch(const hxr_scene* s, const Plan& p, HxrLaunch& L)
 int parts_grid(const hxr_scene* s)   // blocks of the replicating instance launched beside the main kernel: three sixteenths of the machine at three waves per SIMD
 {
 	if (const char* e = getenv("HXR_PARTS_GRID")) return std::max(1, atoi(e));   // developer aid
-	return std::max(1, s->num_cu * HXR_MESH_WAVES * 3 / 16);   // slowest 8-way rank: 1.84 ms at 48 blocks, 1.24-1.34 at 96, 1.22 at 144, 1.20-1.21 at 192 (sum of ranks 9.5 / 9.5 / 9.6)
+	return std::max(1, s->num_cu * HXR_MESH_WAVES * 3 / 16 * (256 / HXR_BLOCK));   // (counted in blocks of HXR_BLOCK threads: 144 of four waves)  slowest 8-way rank: 1.84 ms at 48 blocks, 1.24-1.34 at 96, 1.22 at 144, 1.20-1.21 at 192 (sum of ranks 9.5 / 9.5 / 9.6)
 }
 
 int resident_waves_per_cu(const hxr_scene* s, int mode, bool in_place, uint32_t num_chunks);
@@ -659,10 +659,10 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 	if (L.num_chunks > 0) {
 		// (instrumented launches run variants of other occupancies than the table knows: eight per CU as before)
 		// ... and so do launches a few packets deep per wave (1-spp passes: 0.593 ms with eight, 0.600 with the exact count)
-		int grid = grid_for(s, L.num_chunks, counters || L.num_chunks < (uint32_t)s->num_cu * 16u * 24u ? 8 : resident_waves_per_cu(s, L.mode, !defer && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr), L.num_chunks) / (HXR_BLOCK / 64));
+		int grid = grid_for(s, L.num_chunks, counters || L.num_chunks < (uint32_t)s->num_cu * 16u * 24u ? 8 * (256 / HXR_BLOCK) : resident_waves_per_cu(s, L.mode, !defer && !(s->fanout0 <= 1 && getenv("HXR_STACK1") != nullptr), L.num_chunks) / (HXR_BLOCK / 64));
 		// beside the replicating blocks the main kernel is launched with exactly the blocks that fit the machine with them (three blocks of four waves per CU at
 		// three waves per SIMD): whichever kernel the dispatcher starts first, the other finds its room
-		if (parts_launched) grid = std::max(1, std::min(grid, s->num_cu * HXR_MESH_WAVES - parts_grid(s)));
+		if (parts_launched) grid = std::max(1, std::min(grid, s->num_cu * HXR_MESH_WAVES * (256 / HXR_BLOCK) - parts_grid(s)));
 #define HXR_LAUNCH(CNT, FEAT, WAVES)                                                                                                                      \
 	do {                                                                                                                                                      \
 		if (L.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<CNT, FEAT, WAVES, 1>), dim3(grid), dim3(HXR_BLOCK), 0, st, HXR_KERNEL_ARGS);     \
