@@ -645,8 +645,7 @@ int launch_render(hxr_scene* s, const Plan& p, HxrLaunch& L, bool counters, hipS
 		// waves of the main kernel fill the machine; the caller's stream waits for it after the main kernel
 		int rcs = ensure_parts_stream(s);
 		if (rcs) return rcs;
-		HIP_TRY(hipEventRecord(s->ev_parts_go, st));
-		HIP_TRY(hipStreamWaitEvent(s->parts_stream, s->ev_parts_go, 0));
+		HIP_TRY(hipStreamWaitEvent(s->parts_stream, s->ev_pass[pass][0], 0));   // (the pass's first event, recorded behind the schedule's kernels just above: no event of its own)
 		const HxrLaunch& K = s->parts_launch;
 		const int pgrid = parts_grid(s);
 		if (K.mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(hxr_render_kernel<false, (HXR_F_MESH | HXR_F_TOUCH | HXR_F_REPL), HXR_MESH_WAVES, 1>), dim3(pgrid), dim3(HXR_BLOCK), 0, s->parts_stream, HXR_KERNEL_ARGS_OF(K));
