@@ -1075,7 +1075,9 @@ int render_on_stream(hxr_scene* s, const hxr_frame_params* fp, float* d_out, siz
 		uint32_t heavy_x = 2;    // round 1, frame ms at 2 / 4 / 8 / 16 / 32: 5.13 / 5.07 / 4.96 / 4.82 / 4.99 (5.09 without the list); round 4, with the heavy pixels replicated: 4 / 8 / 16 / 32: 1.75 / 1.82 / 1.83 / 1.82;
 		                         // end of round 4 (medians of 40 frames, twice): 1 / 2 / 3 / 4: 1.83 / 1.74 / 1.78 / 1.80
 		if (const char* e = getenv("HXR_AA_HEAVY_X")) heavy_x = (uint32_t)atoi(e);   // developer aid
-		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * 8u);
+		uint32_t detect_per_cu = 4;   // 1920 x 1080: 78 us at one block per CU, 50 at two, 38 at four, 42 at eight
+		if (const char* e = getenv("HXR_DETECT_PER_CU")) detect_per_cu = (uint32_t)std::max(1, atoi(e));   // developer aid
+		int grid = (int)std::min<uint32_t>((tile_pixels + HXR_BLOCK - 1) / HXR_BLOCK, (uint32_t)s->num_cu * detect_per_cu);
 		hipLaunchKernelGGL(hxr_detect_aa_kernel, dim3(grid), dim3(HXR_BLOCK), 0, st, L, (const float*)frame, fstride, s->d_aa_list, (int32_t*)(s->d_work + 512),
 		                   cost_aware ? (const uint32_t*)s->d_sched_cost : (const uint32_t*)nullptr, (const unsigned long long*)s->d_sched_ctl, L.num_chunks,
 		                   cost_aware ? (uint32_t*)s->d_sched_ctl + 25 : (uint32_t*)nullptr, list_capacity, heavy_x);
