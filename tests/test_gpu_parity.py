@@ -376,6 +376,29 @@ def test_replicated_packets_and_their_blocks_render_the_same_bits(gpu, monkeypat
                 monkeypatch.delenv(k)
 
 
+def test_schedule_thresholds_and_phases_do_not_change_the_frame(gpu, monkeypatch):
+    """End of round 4.  What the schedule lists, from which multiple of the mean cost, in one phase or with the costliest chunks in a phase of their own, and how many
+    blocks are launched are speed matters: a Monte-Carlo frame, a 1-spp frame and an adaptive-AA frame (first and scheduled frames) under each setting against
+    the frame rendered in frame order."""
+    cases = [(hx.overlay_text(640, 360, dof=True, num_samples=16), dict()),
+             (hx.overlay_text(960, 540, want_aa=False), dict(mode=hx.MODE_SINGLE)),
+             (hx.overlay_text(960, 540), dict(mode=hx.MODE_ADAPTIVE_AA))]
+    envs = ({}, {"HXR_SCHED_ONE_PHASE": "1"}, {"HXR_SCHED_FIRST_X": "1"}, {"HXR_SCHED_FIRST_X": "12", "HXR_SCHED_SPLIT_X": "4"}, {"HXR_AA_HEAVY_X": "1"},
+            {"HXR_GRID_PER_CU": "2"}, {"HXR_GRID_PER_CU": "16"}, {"HXR_DETECT_PER_CU": "1"}, {"HXR_MESH_MC_FOUR": "0"}, {"HXR_MESH_MC_FOUR": "1"})
+    for ov, fp in cases:
+        hs = hx.HostScene(scene_path("meshes.hexray"), ov)
+        plain = hx.DeviceScene(hs, adaptive_schedule=False).render(hx.frame_params(**fp))
+        for env in envs:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ds = hx.DeviceScene(hs)
+            for _ in range(3):
+                assert np.array_equal(ds.render(hx.frame_params(**fp)), plain), (fp, env)
+            ds.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_first_frame_schedule_lists_the_same_chunks_for_every_tile_size(gpu):
     """A frame without history starts with the chunks inside the screen rectangles of the nodes that spawn secondary rays
     (hxr_sched_rects_kernel).  Which chunks those are does not depend on how the frame is tiled: a chunk is 64 / spp consecutive pixel
