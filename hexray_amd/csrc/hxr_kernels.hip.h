@@ -2439,7 +2439,8 @@ __global__ __launch_bounds__(HXR_BLOCK, W) void hxr_render_kernel(
 	}
 #ifdef HXR_WAVE_TIMELINE
 	if (P.sched_side && lane == 0) {   // (the far end of the side buffer of the sample parts: 8 MB in, four words per wave)
-		unsigned long long* w = (unsigned long long*)((char*)P.sched_side + (8u << 20)) + 4 * ((size_t)blockIdx.x * (HXR_BLOCK / 64) + wave);
+		// (the replicating blocks launched beside the main kernel write behind its 8192 slots)
+		unsigned long long* w = (unsigned long long*)((char*)P.sched_side + (8u << 20)) + 4 * ((size_t)blockIdx.x * (HXR_BLOCK / 64) + wave + (replicating<COUNT, F> ? 8192u : 0u));
 		w[0] = wt_start; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = wt_longest; w[3] = (wt_longest_at & ((1ull << 48) - 1)) | ((wt_packets & 0xfffull) << 48) | (wt_longest_kind << 60);
 	}
 #endif

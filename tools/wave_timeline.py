@@ -19,13 +19,16 @@ frame = torch.zeros((1080, 1920, 3), dtype=torch.float32, device="cuda")
 p = hx.frame_params(tile_size=64)
 lib = hx.hip_lib()
 lib.hxr_debug_wave_timeline.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-WAVES = 256 * 4 * 4
+WAVES = 16384   # 8192 slots of the main kernel, then those of the replicating blocks launched beside it
 def timeline(ds, label):
-    w = np.zeros((WAVES, 4), dtype=np.uint64)
-    rc = lib.hxr_debug_wave_timeline(ds._s, w.ctypes.data, WAVES)
+    both = np.zeros((WAVES, 4), dtype=np.uint64)
+    rc = lib.hxr_debug_wave_timeline(ds._s, both.ctypes.data, WAVES)
     assert rc == 0
-    w = w[w[:, 1] > 0]
-    t0 = w[:, 0].min()
+    t0_all = both[both[:, 1] > 0][:, 0].min()
+    for name, w in (("", both[:8192]), (" -- the replicating blocks", both[8192:])):
+        w = w[w[:, 1] > 0]
+        if len(w): one_kernel(ds, label + name, w, t0_all)
+def one_kernel(ds, label, w, t0):
     start = (w[:, 0] - t0).astype(np.float64) / 100.0   # us
     end = (w[:, 1] - t0).astype(np.float64) / 100.0
     longest = w[:, 2].astype(np.float64) / 100.0
